@@ -1,0 +1,143 @@
+/*
+ * include/sventt_hip.h -- C ABI of the MI355X (gfx950) NTT engine.
+ *
+ * The reference (Terminus-IMRC/sve-ntt) is a header-only C++20 template
+ * library with no FFI of its own; its boundary for the transform path is
+ *
+ *     sventt::NTT<kernel_type>                       include/sventt/wrapper.hpp:13-83
+ *       NTT(enable_forward, enable_inverse, huge)    wrapper.hpp:34-46
+ *       compute_forward(dst, src) / (dst)            wrapper.hpp:50-65
+ *       compute_inverse(dst, src) / (dst)            wrapper.hpp:67-82
+ *
+ * with kernel_type = IterativeNTT<...> / RecursiveNTT<...> describing the
+ * decomposition at compile time (kernel/iterative.hpp:17-18,
+ * kernel/recursive.hpp:15-17).  This header is the C-ABI those entry points
+ * bind to when the transform runs on the GPU: the C++ facade under
+ * include/sventt/ lowers kernel_type to (modulus, generator, n, n0) and calls
+ * the functions below; any other host language binds the same symbols
+ * (INTEGRATION.md shows the ctypes and C++ bindings).
+ *
+ * Semantics are those of the reference's scalar oracle
+ * (tests/ntt-reference.hpp:43-83):
+ *   forward: natural-order input, bit-reversed output, no scaling;
+ *   inverse: bit-reversed input, natural-order output, scaled by n^{-1};
+ *   every output is the canonical residue in [0, p)  (the reference's SVE
+ *   kernels only guarantee congruence, tests/bench-ntt.cpp:61).
+ * Inputs must be < p (tests/bench-ntt.cpp:31-33 guarantees that there).
+ *
+ * All functions return SVENTT_OK (0) or a negative status; the message of the
+ * last failure on the calling thread is sventt_last_error().
+ * The library needs a HIP device: there is no CPU fallback.
+ */
+#ifndef SVENTT_HIP_H_INCLUDED
+#define SVENTT_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sventt_plan sventt_plan;
+
+enum {
+  SVENTT_OK = 0,
+  SVENTT_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference
+                                       (modulus.hpp:118-120, layer/sve/blocked-generic.hpp:111-116) */
+  SVENTT_ERR_ALLOC = -2,            /* std::bad_alloc (vector.hpp:130-132) */
+  SVENTT_ERR_HIP = -3,              /* a HIP runtime call failed */
+  SVENTT_ERR_LOGIC = -4,            /* std::logic_error (wrapper.hpp:55) */
+  SVENTT_ERR_NO_DEVICE = -5         /* no gfx950 device visible */
+};
+
+/* sventt_plan_create flags */
+enum {
+  SVENTT_FORWARD = 1u, /* NTT(enable_forward=true, ...)   wrapper.hpp:34 */
+  SVENTT_INVERSE = 2u, /* NTT(..., enable_inverse=true)   wrapper.hpp:34 */
+  SVENTT_BOTH = 3u
+};
+
+/*
+ * Replaces the construction of sventt::NTT<kernel_type> (wrapper.hpp:34-46:
+ * sizes and fills the twiddle blob).  p: prime modulus (any odd prime < 2^64
+ * with n | p-1), g: a generator of (Z/p)^* (Modulus<p,g>, modulus.hpp:14),
+ * n: transform length (power of two), batch: number of independent transforms
+ * stored back to back (1 for the reference's API).
+ * n0_log2: log2 of the column length R of the six-step split n = R x C
+ * (RecursiveNTT<..., GenericSVELayer<..., inner_kernel R ...>, ..., true>,
+ * kernel/recursive.hpp:61-75); 0 = choose automatically.
+ */
+int sventt_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2,
+                       uint64_t batch, uint32_t flags, sventt_plan **plan);
+
+void sventt_plan_destroy(sventt_plan *plan);
+
+/*
+ * Replace NTT::compute_forward / compute_inverse (wrapper.hpp:50-82).
+ * dst and src hold n*batch uint64_t each and may alias exactly (dst == src,
+ * the in-place overloads) but not partially.  They may be device pointers
+ * (hipMalloc / torch) -- then the call is asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream) -- or plain host pointers, in which
+ * case the data is staged through a plan-owned device buffer and the call
+ * returns when dst is complete.
+ */
+int sventt_forward(const sventt_plan *plan, uint64_t *dst, const uint64_t *src,
+                   void *stream);
+int sventt_inverse(const sventt_plan *plan, uint64_t *dst, const uint64_t *src,
+                   void *stream);
+
+/*
+ * One pass of the plan at a time, for callers that interleave their own work
+ * (the multi-GPU driver runs the column pass, an all-to-all, then the row
+ * pass).  pass_index in [0, sventt_plan_num_passes).  Device pointers only.
+ */
+int sventt_plan_num_passes(const sventt_plan *plan, int inverse);
+int sventt_run_pass(const sventt_plan *plan, int inverse, int pass_index,
+                    uint64_t *dst, const uint64_t *src, void *stream);
+
+/*
+ * Sharded six-step (no precedent in the reference, which is
+ * single-node shared memory): the global transform has n = R*C points viewed
+ * as R rows x C columns (row-major).  Rank r of `nranks` owns the column block
+ * [r*C/nranks, (r+1)*C/nranks) before the exchange and the row block
+ * [r*R/nranks, (r+1)*R/nranks) after it.
+ *
+ * sventt_sharded_columns: `local` is the rank's R x (C/nranks) slab (row-major,
+ * leading dimension C/nranks); runs the C/nranks column transforms of length R
+ * in place and applies the six-step twiddle omega_n^(bitrev_R(j)*c) with the
+ * GLOBAL column index c (layer/sve/generic.hpp:95-105).  The caller then
+ * exchanges tiles (RCCL all-to-all) so that each rank holds R/nranks full rows,
+ * and finishes with an ordinary batched plan of length C.
+ * Inverse = the mirror (rows first, exchange, then this with inverse != 0,
+ * which also applies the 1/n scaling).
+ */
+int sventt_sharded_plan_create(uint64_t p, uint64_t g, uint64_t n,
+                               uint32_t r_log2, int rank, int nranks,
+                               uint32_t flags, sventt_plan **plan);
+int sventt_sharded_columns(const sventt_plan *plan, int inverse,
+                           uint64_t *local, void *stream);
+
+/* Introspection (get_m(): wrapper.hpp:48; modulus_type: wrapper.hpp:32). */
+uint64_t sventt_plan_n(const sventt_plan *plan);
+uint64_t sventt_plan_batch(const sventt_plan *plan);
+uint64_t sventt_plan_modulus(const sventt_plan *plan);
+/* Human-readable description of the passes ("col 2^11 x T8 | row 2^13"). */
+const char *sventt_plan_describe(const sventt_plan *plan);
+
+/* Element-wise helpers on device or host arrays of `count` residues:
+ * dst[i] = a[i]*b[i] mod p.  The caller of the reference does this between a
+ * forward and an inverse transform
+ * (examples/magic-series/gaussian-polynomial.hpp:201-212). */
+int sventt_pointwise_multiply(const sventt_plan *plan, uint64_t *dst,
+                              const uint64_t *a, const uint64_t *b,
+                              uint64_t count, void *stream);
+
+const char *sventt_last_error(void);
+const char *sventt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SVENTT_HIP_H_INCLUDED */

@@ -1,0 +1,60 @@
+"""Builds libsventt_hip.so (gfx950) in-tree with hipcc.
+
+    python -m sve_ntt_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the
+GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsventt_hip.so")
+SOURCES = ["kernels.hip", "plan.hip"]
+HEADERS = ["field64.h", "tile_ntt.h", "kernels.h", os.path.join(ROOT, "include", "sventt_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
+         "-Wno-unused-parameter", "-fno-gpu-rdc"]
+
+
+def _newest_input() -> float:
+    paths = [os.path.join(CSRC, s) for s in SOURCES]
+    paths += [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def needs_build() -> bool:
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest_input()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,137 @@
+// sve_ntt_amd/csrc/field64.h -- 64-bit prime-field arithmetic for gfx950 (and host).
+//
+// Device counterpart of the reference's PAdic64 modular multiplication
+// (include/sventt/modmul/sve/p-adic-64.hpp:80-115, the bit_width(N)==64
+// branches: every result canonical in [0,N) by compare-and-add) and of its
+// add/subtract (:40-62) and butterflies (:117-246).  The reference streams a
+// second operand w' = w*N^{-1} mod 2^64 beside every twiddle; on gfx950 that
+// would double twiddle traffic while saving nothing (a 64x64->128 product costs
+// the same four v_mad_u64_u32 whether or not its low half is kept), so the
+// quotient is taken from the low half of a*w instead:
+//
+//     t = a*w                   (128 bit, four 32x32 v_mad_u64_u32)
+//     q = lo64(t) * N^{-1}      (mod 2^64)
+//     c = hi64(t) - hi64(q*N)   (+N on borrow)        = a*w*2^-64 mod N
+//
+// which is the same number PAdic64*::multiply_normalize returns.  Twiddles are
+// kept in Montgomery form (w*2^64 mod N), data stays in the plain domain.
+//
+// gfx950 has no 64-bit integer multiplier: everything is built from
+// v_mad_u64_u32 / v_mul_lo_u32 / v_mul_hi_u32 (measured at ~half the v_add_u32
+// rate, tools/ubench_valu.hip), which is what bounds this path.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define F64_HD __host__ __device__ __forceinline__
+#else
+#define F64_HD inline
+#endif
+
+namespace sventt_hip {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+struct Field {
+  u64 N;     // modulus (odd prime, up to 64 bits)
+  u64 Ninv;  // N^{-1} mod 2^64   (Modulus::get_montgomery_inverse, modulus.hpp:36-68)
+};
+
+F64_HD u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+
+// hi:lo = a*b through 32-bit limbs (maps onto four v_mad_u64_u32).
+F64_HD void mul64x64(u64 a, u64 b, u64 &hi, u64 &lo) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 m0 = mad32(a0, b0, 0);
+  const u64 m1 = mad32(a0, b1, m0 >> 32);
+  const u64 m2 = mad32(a1, b0, (u32)m1);
+  hi = mad32(a1, b1, m1 >> 32) + (m2 >> 32);
+  lo = (m2 << 32) | (u32)m0;
+}
+
+F64_HD u64 mulhi64(u64 a, u64 b) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 m0h = ((u64)a0 * b0) >> 32;
+  const u64 m1 = mad32(a0, b1, m0h);
+  const u64 m2 = mad32(a1, b0, (u32)m1);
+  return mad32(a1, b1, m1 >> 32) + (m2 >> 32);
+}
+
+// a * w * 2^-64 mod N, canonical.  Needs w < N; a may be any 64-bit value.
+F64_HD u64 montmul(u64 a, u64 w, const Field &f) {
+  u64 thi, tlo;
+  mul64x64(a, w, thi, tlo);
+  const u32 t0 = (u32)tlo, t1 = (u32)(tlo >> 32);
+  const u32 ni0 = (u32)f.Ninv, ni1 = (u32)(f.Ninv >> 32);
+  const u64 r0 = mad32(t0, ni0, 0);
+  const u32 q0 = (u32)r0;
+  const u32 q1 = (u32)(r0 >> 32) + t0 * ni1 + t1 * ni0;
+  const u64 g = mulhi64(((u64)q1 << 32) | q0, f.N);
+  const u64 c = thi - g;
+  return (thi < g) ? c + f.N : c;
+}
+
+// PAdic64SVE::add, 64-bit-N branch (p-adic-64.hpp:40-50): canonical sum.
+F64_HD u64 addmod(u64 a, u64 b, const Field &f) {
+  const u64 s = a + b;
+  return (s < a || s >= f.N) ? s - f.N : s;
+}
+
+// PAdic64SVE::subtract (p-adic-64.hpp:52-62): canonical difference.
+F64_HD u64 submod(u64 a, u64 b, const Field &f) {
+  const u64 d = a - b;
+  return (a < b) ? d + f.N : d;
+}
+
+// Gentleman-Sande butterfly, PAdic64SVE::butterfly_forward (p-adic-64.hpp:142-178):
+//   (x0, x1) -> (x0 + x1, (x0 - x1) * w)
+F64_HD void butterfly_fwd(u64 &x0, u64 &x1, u64 w, const Field &f) {
+  const u64 s = addmod(x0, x1, f);
+  const u64 d = submod(x0, x1, f);
+  x0 = s;
+  x1 = montmul(d, w, f);
+}
+
+// twiddle-less form (p-adic-64.hpp:117-140)
+F64_HD void butterfly_fwd(u64 &x0, u64 &x1, const Field &f) {
+  const u64 s = addmod(x0, x1, f);
+  x1 = submod(x0, x1, f);
+  x0 = s;
+}
+
+// Cooley-Tukey butterfly, PAdic64SVE::butterfly_inverse (p-adic-64.hpp:225-246):
+//   (x0, x1) -> (x0 + x1*w, x0 - x1*w)
+F64_HD void butterfly_inv(u64 &x0, u64 &x1, u64 w, const Field &f) {
+  const u64 t = montmul(x1, w, f);
+  const u64 s = addmod(x0, t, f);
+  x1 = submod(x0, t, f);
+  x0 = s;
+}
+
+F64_HD void butterfly_inv(u64 &x0, u64 &x1, const Field &f) { butterfly_fwd(x0, x1, f); }
+
+// ---- host-side field helpers (plan construction only) ----------------------
+typedef unsigned __int128 u128;
+inline u64 h_mulmod(u64 a, u64 b, u64 N) { return (u64)(((u128)a * b) % N); }
+inline u64 h_powmod(u64 a, u64 e, u64 N) {
+  u64 r = 1 % N;
+  a %= N;
+  for (; e; e >>= 1) {
+    if (e & 1) r = h_mulmod(r, a, N);
+    a = h_mulmod(a, a, N);
+  }
+  return r;
+}
+inline u64 h_invmod(u64 a, u64 N) { return h_powmod(a, N - 2, N); }
+// N^{-1} mod 2^64 by Newton iteration (same value as modulus.hpp:36-68).
+inline u64 h_montgomery_inverse(u64 N) {
+  u64 x = N;  // correct to 3 bits for odd N
+  for (int i = 0; i < 6; ++i) x *= 2 - N * x;
+  return x;
+}
+inline u64 h_to_montgomery(u64 a, u64 N) { return (u64)((((u128)a) << 64) % N); }
+
+}  // namespace sventt_hip

@@ -1,0 +1,17 @@
+// sve_ntt_amd/csrc/kernels.h -- launch registry shared by kernels.hip and plan.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "registry.h"
+
+namespace sventt_hip {
+
+using KernelEntry = KernelEntryT<hipError_t, hipStream_t>;
+
+const KernelEntry *find_kernel(int kind, int logl, int dir, int flag);
+
+hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, const Field &f,
+                            u64 r2, hipStream_t stream);
+
+}  // namespace sventt_hip

@@ -1,0 +1,262 @@
+// sve_ntt_amd/csrc/plan.hip -- device side of a plan (table upload, pass launches)
+// and the C ABI declared in include/sventt_hip.h.  The pass list itself is built
+// by plan_core.h (host-only).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sventt_hip.h"
+#include "kernels.h"
+#include "plan_core.h"
+
+using namespace sventt_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                            \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess)                                                        \
+      return fail(e_ == hipErrorOutOfMemory ? SVENTT_ERR_ALLOC : SVENTT_ERR_HIP, \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+struct DevicePass {
+  const KernelEntry *kernel = nullptr;
+  u64 *stage = nullptr, *twist_lo = nullptr, *twist_hi = nullptr;
+};
+
+int upload(const std::vector<u64> &host, u64 *&dev) {
+  dev = nullptr;
+  if (host.empty()) return SVENTT_OK;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), host.size() * sizeof(u64)));
+  HIP_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+  return SVENTT_OK;
+}
+
+}  // namespace
+
+struct sventt_plan {
+  HostPlan host;
+  std::vector<DevicePass> fwd, inv;
+  std::string description;
+  // staging for host-pointer calls
+  mutable u64 *staging = nullptr;
+  mutable size_t staging_elems = 0;
+};
+
+namespace {
+
+int check_device() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(SVENTT_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+  return SVENTT_OK;
+}
+
+int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
+  dev.resize(host.size());
+  for (size_t i = 0; i < host.size(); ++i) {
+    const HostPass &h = host[i];
+    DevicePass &d = dev[i];
+    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0);
+    if (!d.kernel) return fail(SVENTT_ERR_LOGIC, "no kernel instantiated for this pass shape");
+    if (d.kernel->f0 != h.f0 || d.kernel->logt != h.logt)
+      return fail(SVENTT_ERR_LOGIC, "planner and kernel registry disagree on the tile shape");
+    int rc;
+    if ((rc = upload(h.stage, d.stage))) return rc;
+    if ((rc = upload(h.twist_lo, d.twist_lo))) return rc;
+    if ((rc = upload(h.twist_hi, d.twist_hi))) return rc;
+  }
+  return SVENTT_OK;
+}
+
+int finish_plan(sventt_plan *pl, int rc, const std::string &err, sventt_plan **out) {
+  if (rc) {
+    delete pl;
+    return fail(rc == PLAN_ERR_INVALID_ARGUMENT ? SVENTT_ERR_INVALID_ARGUMENT : SVENTT_ERR_LOGIC, err);
+  }
+  if ((rc = realize(pl->host.fwd, pl->fwd)) || (rc = realize(pl->host.inv, pl->inv))) {
+    sventt_plan_destroy(pl);
+    return rc;
+  }
+  pl->description = describe_plan(pl->host);
+  // the tables now live on the device
+  for (HostPass &h : pl->host.fwd) h.stage = {}, h.twist_lo = {}, h.twist_hi = {};
+  for (HostPass &h : pl->host.inv) h.stage = {}, h.twist_lo = {}, h.twist_hi = {};
+  *out = pl;
+  return SVENTT_OK;
+}
+
+int run_pass(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const u64 *src,
+             hipStream_t stream) {
+  const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[index];
+  const DevicePass &d = (inverse ? pl->inv : pl->fwd)[index];
+  const PassArgs a = make_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi);
+  HIP_TRY(d.kernel->launch(a, (u32)h.grid, stream));
+  return SVENTT_OK;
+}
+
+bool is_device_pointer(const void *p) {
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
+         attr.type == hipMemoryTypeArray;
+}
+
+int transform_device(const sventt_plan *pl, bool inverse, u64 *dst, const u64 *src,
+                     hipStream_t stream) {
+  const size_t npass = (inverse ? pl->inv : pl->fwd).size();
+  if (pl->host.n == 1) {
+    if (dst != src)
+      HIP_TRY(hipMemcpyAsync(dst, src, pl->host.total * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    return SVENTT_OK;
+  }
+  const u64 *in = src;
+  for (size_t i = 0; i < npass; ++i) {
+    int rc = run_pass(pl, inverse, i, dst, in, stream);
+    if (rc) return rc;
+    in = dst;
+  }
+  return SVENTT_OK;
+}
+
+int transform(const sventt_plan *pl, bool inverse, u64 *dst, const u64 *src, void *stream_) {
+  if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (pl->host.sharded) return fail(SVENTT_ERR_LOGIC, "sharded plans run through sventt_sharded_columns");
+  if (!(pl->host.flags & (inverse ? PLAN_INVERSE : PLAN_FORWARD)))
+    return fail(SVENTT_ERR_LOGIC, inverse ? "plan was created without SVENTT_INVERSE"
+                                          : "plan was created without SVENTT_FORWARD");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool ddst = is_device_pointer(dst), dsrc = is_device_pointer(src);
+  if (ddst && dsrc) return transform_device(pl, inverse, dst, src, stream);
+  if (ddst != dsrc)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "dst and src must both be device or both be host pointers");
+  // Host pointers (what NTT::compute_* of the reference take, wrapper.hpp:50-82):
+  // stage through a plan-owned device buffer; returns when dst is complete.
+  const size_t bytes = pl->host.total * sizeof(u64);
+  if (pl->staging_elems < pl->host.total) {
+    if (pl->staging) (void)hipFree(pl->staging);
+    pl->staging = nullptr;
+    pl->staging_elems = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->staging), bytes));
+    pl->staging_elems = pl->host.total;
+  }
+  HIP_TRY(hipMemcpyAsync(pl->staging, src, bytes, hipMemcpyHostToDevice, stream));
+  int rc = transform_device(pl, inverse, pl->staging, pl->staging, stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst, pl->staging, bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return SVENTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sventt_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch,
+                       uint32_t flags, sventt_plan **out) {
+  if (!out) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null plan pointer");
+  *out = nullptr;
+  sventt_plan *pl = new (std::nothrow) sventt_plan;
+  if (!pl) return fail(SVENTT_ERR_ALLOC, "out of host memory");
+  std::string err;
+  int rc = build_plan(pl->host, p, g, n, n0_log2, batch, flags, err);
+  if (!rc && check_device()) {
+    delete pl;
+    return SVENTT_ERR_NO_DEVICE;
+  }
+  return finish_plan(pl, rc, err, out);
+}
+
+int sventt_sharded_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank,
+                               int nranks, uint32_t flags, sventt_plan **out) {
+  if (!out) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null plan pointer");
+  *out = nullptr;
+  sventt_plan *pl = new (std::nothrow) sventt_plan;
+  if (!pl) return fail(SVENTT_ERR_ALLOC, "out of host memory");
+  std::string err;
+  int rc = build_sharded_plan(pl->host, p, g, n, r_log2, rank, nranks, flags, err);
+  if (!rc && check_device()) {
+    delete pl;
+    return SVENTT_ERR_NO_DEVICE;
+  }
+  return finish_plan(pl, rc, err, out);
+}
+
+void sventt_plan_destroy(sventt_plan *pl) {
+  if (!pl) return;
+  for (std::vector<DevicePass> *v : {&pl->fwd, &pl->inv})
+    for (DevicePass &d : *v) {
+      if (d.stage) (void)hipFree(d.stage);
+      if (d.twist_lo) (void)hipFree(d.twist_lo);
+      if (d.twist_hi) (void)hipFree(d.twist_hi);
+    }
+  if (pl->staging) (void)hipFree(pl->staging);
+  delete pl;
+}
+
+int sventt_forward(const sventt_plan *pl, uint64_t *dst, const uint64_t *src, void *stream) {
+  return transform(pl, false, dst, src, stream);
+}
+
+int sventt_inverse(const sventt_plan *pl, uint64_t *dst, const uint64_t *src, void *stream) {
+  return transform(pl, true, dst, src, stream);
+}
+
+int sventt_plan_num_passes(const sventt_plan *pl, int inverse) {
+  if (!pl) return 0;
+  return (int)(inverse ? pl->inv.size() : pl->fwd.size());
+}
+
+int sventt_run_pass(const sventt_plan *pl, int inverse, int pass_index, uint64_t *dst,
+                    const uint64_t *src, void *stream) {
+  if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t npass = (inverse ? pl->inv : pl->fwd).size();
+  if (pass_index < 0 || (size_t)pass_index >= npass)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "pass index out of range");
+  return run_pass(pl, inverse != 0, (size_t)pass_index, dst, src, static_cast<hipStream_t>(stream));
+}
+
+int sventt_sharded_columns(const sventt_plan *pl, int inverse, uint64_t *local, void *stream) {
+  if (!pl || !local) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!pl->host.sharded) return fail(SVENTT_ERR_LOGIC, "not a sharded plan");
+  if ((inverse ? pl->inv : pl->fwd).empty())
+    return fail(SVENTT_ERR_LOGIC, "direction not enabled in this plan");
+  return run_pass(pl, inverse != 0, 0, local, local, static_cast<hipStream_t>(stream));
+}
+
+uint64_t sventt_plan_n(const sventt_plan *pl) { return pl ? pl->host.n : 0; }
+uint64_t sventt_plan_batch(const sventt_plan *pl) { return pl ? pl->host.batch : 0; }
+uint64_t sventt_plan_modulus(const sventt_plan *pl) { return pl ? pl->host.f.N : 0; }
+const char *sventt_plan_describe(const sventt_plan *pl) { return pl ? pl->description.c_str() : ""; }
+
+int sventt_pointwise_multiply(const sventt_plan *pl, uint64_t *dst, const uint64_t *a,
+                              const uint64_t *b, uint64_t count, void *stream) {
+  if (!pl || !dst || !a || !b) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!is_device_pointer(dst) || !is_device_pointer(a) || !is_device_pointer(b))
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "pointwise multiply takes device pointers");
+  HIP_TRY(launch_pointwise(dst, a, b, count, pl->host.f, pl->host.r2,
+                           static_cast<hipStream_t>(stream)));
+  return SVENTT_OK;
+}
+
+const char *sventt_last_error(void) { return g_last_error.c_str(); }
+const char *sventt_version(void) { return "sventt-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

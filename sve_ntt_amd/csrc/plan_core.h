@@ -1,0 +1,369 @@
+// sve_ntt_amd/csrc/plan_core.h -- host-only plan description (no HIP calls).
+//
+// A plan is the runtime form of the reference's compile-time kernel_type
+// (kernel/recursive.hpp:15-17 over layer/sve/[blocked-]generic.hpp): a list of
+// passes.  Forward:
+//     COL(L0, S0) -> COL(L1, S1) -> ... -> ROW(Lk)       n = L0*L1*...*Lk
+// COL(L, S): for every contiguous block of M = L*S elements viewed as L rows x
+// S columns, run the S column transforms of length L in place and multiply
+// row j by omega_M^(bitrev_L(j)*c) (six-step twiddle, layer/sve/generic.hpp:
+// 95-105).  ROW(L): transform every contiguous run of L elements.  Each pass
+// reads and writes every element exactly once (16 bytes of HBM traffic per
+// element per pass).  The inverse plan is the mirror image with inverse roots;
+// the 1/n scaling rides on a multiplication that exists anyway (the outermost
+// inverse twiddle, or the top stage of a single-pass plan).
+//
+// plan.hip uploads these tables and launches kernels; tests/cpu_sim replays the
+// same passes sequentially on the host (test-only).
+#pragma once
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "registry.h"
+
+namespace sventt_hip {
+
+struct HostPass {
+  int kind = KIND_ROW, logl = 0;
+  bool inverse = false, flag = false;
+  u64 istride = 1;  // COL: S
+  u64 block = 0;    // COL: M = L*S
+  u64 grid = 0;
+  int f0 = 0, logt = 0;
+  std::vector<u64> stage, twist_lo, twist_hi;
+  u32 twist_shift = 0;
+  u64 twist_col_offset = 0;
+  u64 scale = 0;  // Montgomery form
+};
+
+struct HostPlan {
+  Field f{};
+  u64 g = 0, n = 0, batch = 1, total = 0;
+  u32 flags = 0;
+  u64 r2 = 0;  // 2^128 mod N
+  std::vector<HostPass> fwd, inv;
+  bool sharded = false;
+  int rank = 0, nranks = 1;
+  u64 local_cols = 0;
+};
+
+enum : int {
+  PLAN_OK = 0,
+  PLAN_ERR_INVALID_ARGUMENT = -1,
+  PLAN_ERR_LOGIC = -4,
+};
+enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u };
+
+inline bool is_pow2(u64 x) { return x && !(x & (x - 1)); }
+inline int ilog2_u64(u64 x) {
+  int l = 0;
+  while ((x >> l) > 1) ++l;
+  return l;
+}
+
+// stage tables of a length-2^logl transform: stage bit p at [2^p-1, 2^(p+1)-1),
+// entry j = root_{2^(p+1)}^j in Montgomery form; `top_scale` (plain) multiplies
+// the top stage's entries (inverse ROW passes that fold 1/L).
+inline std::vector<u64> build_stage_table(const Field &f, u64 gen, int logl, bool inverse,
+                                          u64 top_scale) {
+  const u64 N = f.N;
+  const u64 L = 1ull << logl;
+  std::vector<u64> t(L > 1 ? L - 1 : 1, 0);
+  for (int p = 0; p < logl; ++p) {
+    const u64 order = 2ull << p;
+    u64 w = h_powmod(gen, (N - 1) / order, N);
+    if (inverse) w = h_invmod(w, N);
+    u64 cur = (p == logl - 1) ? top_scale % N : 1;
+    for (u64 j = 0; j < (1ull << p); ++j) {
+      t[(1ull << p) - 1 + j] = h_to_montgomery(cur, N);
+      cur = h_mulmod(cur, w, N);
+    }
+  }
+  return t;
+}
+
+// omega_M^e = hi[e >> shift] * lo[e & mask]; `scale` (plain) is folded into hi.
+inline void build_twist_tables(const Field &f, u64 gen, int logm, bool inverse, u64 scale,
+                               std::vector<u64> &lo, std::vector<u64> &hi, u32 &shift) {
+  const u64 N = f.N;
+  u64 w = h_powmod(gen, (N - 1) >> logm, N);
+  if (inverse) w = h_invmod(w, N);
+  shift = (u32)((logm + 1) / 2);
+  lo.resize(1ull << shift);
+  hi.resize(1ull << (logm - (int)shift));
+  u64 cur = 1;
+  for (u64 i = 0; i < lo.size(); ++i) {
+    lo[i] = h_to_montgomery(cur, N);
+    cur = h_mulmod(cur, w, N);
+  }
+  const u64 wbig = h_powmod(w, 1ull << shift, N);
+  cur = scale % N;
+  for (u64 i = 0; i < hi.size(); ++i) {
+    hi[i] = h_to_montgomery(cur, N);
+    cur = h_mulmod(cur, wbig, N);
+  }
+}
+
+inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, u64 S, bool inverse,
+                          bool flag, u64 scale_plain, u64 col_offset, int twist_order_log2,
+                          std::string &err) {
+  const Field &f = pl.f;
+  ps.kind = kind;
+  ps.logl = logl;
+  ps.inverse = inverse;
+  ps.flag = flag;
+  ps.istride = S;
+  ps.block = S << logl;
+  ps.twist_col_offset = col_offset;
+  const bool fold_row_scale = (kind == KIND_ROW) && inverse && flag;
+  ps.stage = build_stage_table(f, pl.g, logl, inverse, fold_row_scale ? scale_plain : 1);
+  if (fold_row_scale) ps.scale = h_to_montgomery(scale_plain % f.N, f.N);
+  u64 tiles;
+  if (kind == KIND_COL) {
+    if (logl > MAX_COL_LOGL) {
+      err = "column pass longer than one workgroup can hold";
+      return PLAN_ERR_LOGIC;
+    }
+    build_twist_tables(f, pl.g, twist_order_log2, inverse, inverse ? scale_plain : 1, ps.twist_lo,
+                       ps.twist_hi, ps.twist_shift);
+    ps.f0 = registry_col_f0(logl);
+    ps.logt = ps.f0 + logl;
+    const u64 T = 1ull << ps.f0;
+    if (S % T != 0) {
+      err = "column count is not a multiple of the tile width";
+      return PLAN_ERR_INVALID_ARGUMENT;
+    }
+    tiles = (pl.total / ps.block) * (S / T);
+  } else {
+    if (logl > MAX_ROW_LOGL) {
+      err = "row pass longer than one workgroup can hold";
+      return PLAN_ERR_LOGIC;
+    }
+    ps.f0 = 0;
+    ps.logt = registry_row_logt(logl);
+    const u64 tile = 1ull << ps.logt;
+    tiles = (pl.total + tile - 1) / tile;
+  }
+  if (tiles > 0x7fffffffull) {
+    err = "too many tiles for one launch";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  ps.grid = tiles;
+  return PLAN_OK;
+}
+
+// Split log2(n) into pass lengths: every COL pass <= MAX_COL_LOGL, the final ROW
+// pass <= MAX_ROW_LOGL.  n0_log2 (if non-zero) fixes the first COL pass (the R
+// of the reference's n = R x C six-step, kernel/recursive.hpp:61-75).
+inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row, std::string &err) {
+  cols.clear();
+  int rem = logn;
+  if (n0_log2 != 0) {
+    if ((int)n0_log2 >= logn || (int)n0_log2 > MAX_COL_LOGL) {
+      err = "n0_log2 out of range for this transform length";
+      return PLAN_ERR_INVALID_ARGUMENT;
+    }
+    cols.push_back((int)n0_log2);
+    rem -= (int)n0_log2;
+  }
+  if (rem <= MAX_ROW_LOGL && (n0_log2 != 0 || logn <= MAX_ROW_LOGL)) {
+    row = rem;
+    return PLAN_OK;
+  }
+  // Widest smallest tile of the column pass is 2^3 columns: the row pass (the
+  // block of contiguous elements below the innermost column pass) is >= 2^3.
+  row = rem - MAX_COL_LOGL;
+  const int half = (rem + 1) / 2;
+  if (row < half) row = half;
+  if (row > MAX_ROW_LOGL) row = MAX_ROW_LOGL;
+  rem -= row;
+  while (rem > 0) {
+    const int npass = (rem + MAX_COL_LOGL - 1) / MAX_COL_LOGL;
+    const int c = (rem + npass - 1) / npass;
+    cols.push_back(c);
+    rem -= c;
+  }
+  return PLAN_OK;
+}
+
+inline int validate_field(u64 p, u64 g, u64 n, std::string &err) {
+  if (p < 3 || (p & 1) == 0) {
+    err = "modulus must be an odd prime";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if (!is_pow2(n)) {
+    err = "Transform length must be a power of two for now";  // tests/ntt-reference.hpp:38-40
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if ((p - 1) % n != 0) {
+    err = "the field has no such root";  // modulus.hpp:118-120
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if (g == 0 || g >= p) {
+    err = "generator out of range";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if (n > 1) {
+    const u64 w = h_powmod(g, (p - 1) / n, p);
+    if (h_powmod(w, n / 2, p) != p - 1) {
+      err = "g does not generate a root of unity of order n";
+      return PLAN_ERR_INVALID_ARGUMENT;
+    }
+  }
+  return PLAN_OK;
+}
+
+inline void init_field(HostPlan &pl, u64 p, u64 g) {
+  pl.f.N = p;
+  pl.f.Ninv = h_montgomery_inverse(p);
+  pl.g = g;
+  pl.r2 = h_to_montgomery(h_to_montgomery(1, p), p);
+}
+
+inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch, u32 flags,
+                      std::string &err) {
+  int rc = validate_field(p, g, n, err);
+  if (rc) return rc;
+  if (batch == 0) {
+    err = "batch must be at least 1";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if ((flags & (PLAN_FORWARD | PLAN_INVERSE)) == 0) {
+    err = "neither direction enabled";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if (n > (~0ull) / batch / 8) {
+    err = "n*batch overflows";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  init_field(pl, p, g);
+  pl.n = n;
+  pl.batch = batch;
+  pl.total = n * batch;
+  pl.flags = flags;
+  const int logn = ilog2_u64(n);
+  if (logn == 0) return PLAN_OK;
+  std::vector<int> cols;
+  int row = 0;
+  if ((rc = choose_split(logn, n0_log2, cols, row, err))) return rc;
+  const u64 ninv = h_invmod(n % p, p);
+  if (flags & PLAN_FORWARD) {
+    int rem = logn;
+    for (size_t i = 0; i < cols.size(); ++i) {
+      pl.fwd.emplace_back();
+      rem -= cols[i];
+      if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_COL, cols[i], 1ull << rem, false, true, 1, 0,
+                               rem + cols[i], err)))
+        return rc;
+    }
+    if (row > 0) {
+      pl.fwd.emplace_back();
+      if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_ROW, row, 1, false, false, 1, 0, 0, err)))
+        return rc;
+    }
+  }
+  if (flags & PLAN_INVERSE) {
+    // mirror: ROW first, then the COL passes innermost -> outermost
+    if (row > 0) {
+      pl.inv.emplace_back();
+      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_ROW, row, 1, true, cols.empty(),
+                               cols.empty() ? ninv : 1, 0, 0, err)))
+        return rc;
+    }
+    int rem = row;
+    for (size_t k = cols.size(); k-- > 0;) {
+      pl.inv.emplace_back();
+      const bool outermost = (k == 0);
+      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_COL, cols[k], 1ull << rem, true, true,
+                               outermost ? ninv : 1, 0, rem + cols[k], err)))
+        return rc;
+      rem += cols[k];
+    }
+  }
+  return PLAN_OK;
+}
+
+// One rank's column pass of the sharded six-step (include/sventt_hip.h).
+inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int rank, int nranks,
+                              u32 flags, std::string &err) {
+  int rc = validate_field(p, g, n, err);
+  if (rc) return rc;
+  if (nranks < 1 || rank < 0 || rank >= nranks || !is_pow2((u64)nranks)) {
+    err = "rank/nranks invalid (nranks must be a power of two)";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const int logn = ilog2_u64(n);
+  if (r_log2 == 0 || (int)r_log2 >= logn || (int)r_log2 > MAX_COL_LOGL) {
+    err = "r_log2 out of range";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const u64 C = n >> r_log2;
+  if (C % (u64)nranks != 0) {
+    err = "columns do not divide over the ranks";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  init_field(pl, p, g);
+  pl.n = n;
+  pl.batch = 1;
+  pl.flags = flags;
+  pl.sharded = true;
+  pl.rank = rank;
+  pl.nranks = nranks;
+  pl.local_cols = C / (u64)nranks;
+  pl.total = pl.local_cols << r_log2;
+  const u64 ninv = h_invmod(n % p, p);
+  const u64 off = pl.local_cols * (u64)rank;
+  if (flags & PLAN_FORWARD) {
+    pl.fwd.emplace_back();
+    if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_COL, (int)r_log2, pl.local_cols, false, true, 1,
+                             off, logn, err)))
+      return rc;
+  }
+  if (flags & PLAN_INVERSE) {
+    pl.inv.emplace_back();
+    if ((rc = make_host_pass(pl, pl.inv.back(), KIND_COL, (int)r_log2, pl.local_cols, true, true,
+                             ninv, off, logn, err)))
+      return rc;
+  }
+  return PLAN_OK;
+}
+
+// Kernel arguments of a pass, given where its tables live.
+inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, const u64 *src,
+                          const u64 *stage, const u64 *twist_lo, const u64 *twist_hi) {
+  PassArgs a{};
+  a.dst = dst;
+  a.src = src;
+  a.f = pl.f;
+  a.stage_tw = stage;
+  a.total = pl.total;
+  a.istride = ps.istride;
+  a.ostride = ps.block;
+  a.tiles_per_outer = (ps.kind == KIND_COL) ? (u32)(ps.istride >> ps.f0) : 0;
+  a.twist_lo = twist_lo;
+  a.twist_hi = twist_hi;
+  a.twist_shift = ps.twist_shift;
+  a.twist_col_offset = ps.twist_col_offset;
+  a.scale = ps.scale;
+  return a;
+}
+
+inline std::string describe_plan(const HostPlan &pl) {
+  std::string d;
+  char buf[96];
+  const std::vector<HostPass> &v = pl.fwd.empty() ? pl.inv : pl.fwd;
+  for (const HostPass &p : v) {
+    if (!d.empty()) d += " | ";
+    if (p.kind == KIND_COL)
+      snprintf(buf, sizeof buf, "col 2^%d x T%d (stride %llu)", p.logl, 1 << p.f0,
+               (unsigned long long)p.istride);
+    else
+      snprintf(buf, sizeof buf, "row 2^%d (tile 2^%d)", p.logl, p.logt);
+    d += buf;
+  }
+  return d;
+}
+
+}  // namespace sventt_hip

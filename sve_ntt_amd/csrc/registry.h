@@ -1,0 +1,98 @@
+// sve_ntt_amd/csrc/registry.h -- which TileNTT instantiation serves which pass.
+//
+// Parameterised by the launcher so that the same table drives the HIP kernels
+// (kernels.hip) and the sequential emulation used by the CPU-side tests
+// (tests/cpu_sim/sim.cpp; test-only, never linked into the product).
+#pragma once
+
+#include "tile_ntt.h"
+
+namespace sventt_hip {
+
+enum : int { KIND_ROW = 0, KIND_COL = 1 };
+
+constexpr int MAX_ROW_LOGL = 13;  // longest transform one workgroup keeps on chip (64 KiB of LDS)
+constexpr int MAX_COL_LOGL = 11;  // longest strided column (x 8 columns = 128 KiB of LDS)
+
+// Step lists: radix-16 steps from the top stage down (E = 16 elements per
+// thread), remainder last.
+template <int LOGL> struct DefaultSteps;
+template <> struct DefaultSteps<1> { using type = Steps<1>; };
+template <> struct DefaultSteps<2> { using type = Steps<2>; };
+template <> struct DefaultSteps<3> { using type = Steps<3>; };
+template <> struct DefaultSteps<4> { using type = Steps<4>; };
+template <> struct DefaultSteps<5> { using type = Steps<4, 1>; };
+template <> struct DefaultSteps<6> { using type = Steps<4, 2>; };
+template <> struct DefaultSteps<7> { using type = Steps<4, 3>; };
+template <> struct DefaultSteps<8> { using type = Steps<4, 4>; };
+template <> struct DefaultSteps<9> { using type = Steps<4, 4, 1>; };
+template <> struct DefaultSteps<10> { using type = Steps<4, 4, 2>; };
+template <> struct DefaultSteps<11> { using type = Steps<4, 4, 3>; };
+template <> struct DefaultSteps<12> { using type = Steps<4, 4, 4>; };
+template <> struct DefaultSteps<13> { using type = Steps<4, 4, 4, 1>; };
+
+constexpr int REG_LOGE = 4;
+// ROW tiles are 2^12 elements (256 threads) unless the row itself is longer.
+constexpr int row_logt(int logl) { return logl > 12 ? logl : 12; }
+// COL tiles hold T = 8 adjacent columns (64-byte HBM segments); short columns
+// afford more so that the tile still has 2^12 elements.
+constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
+
+template <int LOGL, int MODE, bool FLAG>
+using RowTile =
+    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename DefaultSteps<LOGL>::type>;
+template <int LOGL, int MODE>
+using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
+                        typename DefaultSteps<LOGL>::type>;
+
+template <class Status, class Stream> struct KernelEntryT {
+  int kind, logl, dir, flag;
+  int logt, f0, threads;
+  Status (*launch)(const PassArgs &, u32 grid, Stream);
+};
+
+template <class TN, class Entry, template <class> class Launcher>
+Entry make_entry(int kind, int dir, int flag) {
+  Entry e;
+  e.kind = kind;
+  e.logl = TN::LOGL;
+  e.dir = dir;
+  e.flag = flag;
+  e.logt = TN::LOGT;
+  e.f0 = TN::F0;
+  e.threads = TN::NT;
+  e.launch = &Launcher<TN>::launch;
+  return e;
+}
+
+#define SVENTT_ROW_ENTRIES(L)                                                        \
+  make_entry<RowTile<L, MODE_FWD, false>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0),   \
+  make_entry<RowTile<L, MODE_INV, false>, Entry, Launcher>(KIND_ROW, MODE_INV, 0),   \
+  make_entry<RowTile<L, MODE_INV, true>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
+#define SVENTT_COL_ENTRIES(L)                                             \
+  make_entry<ColTile<L, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1), \
+  make_entry<ColTile<L, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
+
+template <class Entry, template <class> class Launcher>
+const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag) {
+  static const Entry table[] = {
+      SVENTT_ROW_ENTRIES(1),  SVENTT_ROW_ENTRIES(2),  SVENTT_ROW_ENTRIES(3),
+      SVENTT_ROW_ENTRIES(4),  SVENTT_ROW_ENTRIES(5),  SVENTT_ROW_ENTRIES(6),
+      SVENTT_ROW_ENTRIES(7),  SVENTT_ROW_ENTRIES(8),  SVENTT_ROW_ENTRIES(9),
+      SVENTT_ROW_ENTRIES(10), SVENTT_ROW_ENTRIES(11), SVENTT_ROW_ENTRIES(12),
+      SVENTT_ROW_ENTRIES(13),
+      SVENTT_COL_ENTRIES(1),  SVENTT_COL_ENTRIES(2),  SVENTT_COL_ENTRIES(3),
+      SVENTT_COL_ENTRIES(4),  SVENTT_COL_ENTRIES(5),  SVENTT_COL_ENTRIES(6),
+      SVENTT_COL_ENTRIES(7),  SVENTT_COL_ENTRIES(8),  SVENTT_COL_ENTRIES(9),
+      SVENTT_COL_ENTRIES(10), SVENTT_COL_ENTRIES(11),
+  };
+  for (const Entry &e : table)
+    if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag) return &e;
+  return nullptr;
+}
+
+// Shape facts the host planner needs without instantiating anything.
+inline int registry_col_f0(int logl) { return col_f0(logl); }
+inline int registry_row_logt(int logl) { return row_logt(logl); }
+
+}  // namespace sventt_hip

@@ -1,0 +1,230 @@
+// sve_ntt_amd/csrc/tile_ntt.h -- one workgroup's share of an NTT pass.
+//
+// A pass of the plan (plan.h) cuts the data into TILES of 2^LOGT elements; one
+// workgroup owns one tile for the whole pass: every element is read from HBM
+// once, all of the pass's butterfly stages run on chip, every element is
+// written once.  This is the GPU shape of the reference's per-thread
+// cache-resident block (layer/sve/blocked-generic.hpp:139-154: "transpose a
+// block of columns into a padded L1/L2 buffer, run the inner NTTs, transpose
+// back") and of its inner IterativeNTT (kernel/iterative.hpp:43-54); there is
+// no separate transposition, the tile's addressing *is* the transpose.
+//
+// Tile index space.  A tile element has a LOGT-bit index I.  The transform
+// acts on the bit field [F0, F0+LOGL) of I; the remaining bits number the
+// independent sequences in the tile:
+//   ROW tile (F0 == 0):  I = b*L + i          2^(LOGT-LOGL) contiguous rows
+//   COL tile (F0  > 0):  I = i*T + b          T = 2^F0 adjacent columns, row
+//                                             i is `istride` elements away in HBM
+//
+// Stages are fused into STEPS of k <= LOGE stages (the reference's
+// RadixTwo/Four/EightSVELayer are k = 1, 2, 3: layer/sve/radix-*.hpp).  In a
+// step every thread holds E = 2^LOGE elements in registers, grouped as
+// E/2^k radix-2^k sets, and runs k butterfly stages on them with no exchange;
+// between steps the tile is re-distributed through LDS (one ds_write_b64 and
+// one ds_read_b64 per element, XOR-swizzled against bank conflicts).  The
+// first step reads HBM directly and the last one writes HBM directly.
+//
+// Forward = decimation in frequency, natural in / bit-reversed out, stage
+// twiddle omega_{2h}^(i mod h) as in tests/ntt-reference.hpp:43-61 of the
+// reference; inverse = the exact mirror (:63-83).
+//
+// The same code is compiled for the host by tests/cpu_sim (a sequential
+// emulation used to debug index arithmetic without a GPU; test-only).
+#pragma once
+
+#include "field64.h"
+
+namespace sventt_hip {
+
+enum : int { MODE_FWD = 0, MODE_INV = 1 };
+
+// Arguments of one pass (passed by value to the kernel: lives in SGPRs).
+struct PassArgs {
+  u64 *dst;
+  const u64 *src;
+  Field f;
+  const u64 *stage_tw;  // stage tables of the pass length L: stage bit p (span 2^p) at
+                        // [2^p - 1, 2^(p+1) - 1): omega_{2^(p+1)}^j, Montgomery form
+  u64 total;            // elements in the whole array (tiles past it are masked)
+  // COL geometry: element (o, i, c) lives at o*ostride + i*istride + c
+  u64 istride;
+  u64 ostride;
+  u32 tiles_per_outer;  // istride / T
+  // twist of the pass (six-step twiddle, layer/sve/generic.hpp:95-105,169-188):
+  // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
+  const u64 *twist_lo;
+  const u64 *twist_hi;
+  u32 twist_shift;
+  u64 twist_col_offset; // added to the column index (rank offset of a sharded column pass)
+  u64 scale;            // ROW inverse with FLAG: L^{-1} (Montgomery form)
+};
+
+template <int... KS> struct Steps {
+  static constexpr int n = sizeof...(KS);
+  static constexpr int k[sizeof...(KS)] = {KS...};
+  static constexpr int sum(int upto) {
+    int s = 0;
+    for (int i = 0; i < upto; ++i) s += k[i];
+    return s;
+  }
+};
+
+// XOR swizzle of the LDS image: bank bits 0..4 (8-byte words) are mixed with
+// index bits 4..8 so that the strided element sets of every step fall on
+// distinct banks (checked by tests/test_lds_swizzle.py).
+F64_HD u32 lds_phys(u32 I) { return I ^ ((I >> 4) & 31u); }
+
+F64_HD u32 bitrev32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x);
+#else
+  x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+  x = ((x & 0x33333333u) << 2) | ((x >> 2) & 0x33333333u);
+  x = ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu);
+  x = ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu);
+  return (x << 16) | (x >> 16);
+#endif
+}
+
+// FLAG: COL tiles -> apply the pass twist (store side forward, load side inverse);
+//       ROW inverse tiles -> fold the 1/L scaling into the top stage.
+template <int LOGT_, int F0_, int LOGL_, int LOGE_, int MODE_, bool FLAG_, class STEPS_>
+struct TileNTT {
+  static constexpr int LOGT = LOGT_, F0 = F0_, LOGL = LOGL_, LOGE = LOGE_, MODE = MODE_;
+  static constexpr bool FLAG = FLAG_;
+  using STEPS = STEPS_;
+  static constexpr int E = 1 << LOGE;
+  static constexpr int NT = 1 << (LOGT - LOGE);
+  static constexpr bool COL = F0 > 0;
+  static constexpr int T = 1 << F0;
+  static constexpr int NSTEPS = STEPS::n;
+  static_assert(STEPS::sum(NSTEPS) == LOGL, "steps must cover every stage once");
+  static_assert(LOGT >= LOGE && F0 + LOGL <= LOGT, "tile too small");
+  static_assert(!COL || F0 + LOGL == LOGT, "a COL tile holds whole columns");
+
+  struct Tile {
+    u64 base;    // element offset of the tile in HBM
+    u32 c0;      // COL: first column (index inside the M-point sub-transform)
+    bool live;   // false: whole tile lies past the end (ROW, ragged batch)
+  };
+
+  F64_HD static Tile locate(const PassArgs &a, u32 block) {
+    Tile t;
+    if constexpr (COL) {
+      const u32 o = block / a.tiles_per_outer, ct = block - o * a.tiles_per_outer;
+      t.c0 = ct * (u32)T;
+      t.base = (u64)o * a.ostride + t.c0;
+      t.live = true;
+    } else {
+      t.c0 = 0;
+      t.base = (u64)block << LOGT;
+      t.live = t.base < a.total;
+    }
+    return t;
+  }
+
+  F64_HD static u64 gaddr(const PassArgs &a, const Tile &t, u32 I) {
+    if constexpr (COL)
+      return t.base + (u64)(I >> F0) * a.istride + (I & (u32)(T - 1));
+    else
+      return t.base + I;
+  }
+
+  F64_HD static bool in_range(const PassArgs &a, const Tile &t, u32 I) {
+    if constexpr (COL)
+      return true;
+    else
+      return t.base + I < a.total;
+  }
+
+  // six-step twiddle of element I: omega_M^(bitrev_L(i) * c)
+  F64_HD static u64 twist(const PassArgs &a, const Tile &t, u32 I) {
+    const u32 i = I >> F0;
+    const u32 br = LOGL ? (bitrev32(i) >> (32 - LOGL)) : 0u;
+    const u64 e = (u64)br * (a.twist_col_offset + t.c0 + (I & (u32)(T - 1)));
+    const u64 lo = a.twist_lo[e & ((1ull << a.twist_shift) - 1)];
+    const u64 hi = a.twist_hi[e >> a.twist_shift];
+    return montmul(hi, lo, a.f);
+  }
+
+  // One step for one thread.  `first`/`last` say whether this step touches HBM.
+  template <int SI>
+  F64_HD static void step(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
+    constexpr int k = STEPS::k[SI];
+    constexpr int HI = LOGL - STEPS::sum(SI);  // field-relative top bit (exclusive)
+    constexpr int LO = HI - k;
+    constexpr int lo = F0 + LO, hi = F0 + HI;
+    constexpr int R = 1 << k;
+    constexpr int G = E >> k;
+    static_assert(k >= 1 && k <= LOGE, "step radix out of range");
+    constexpr bool from_hbm = (MODE == MODE_FWD) ? (SI == 0) : (SI == NSTEPS - 1);
+    constexpr bool to_hbm = (MODE == MODE_FWD) ? (SI == NSTEPS - 1) : (SI == 0);
+
+    u64 x[E];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const u32 s = tid + (u32)g * NT;
+      const u32 s_low = s & ((1u << lo) - 1u);
+      const u32 I0 = ((s >> lo) << hi) | s_low;
+      // ---- gather ----------------------------------------------------------
+#pragma unroll
+      for (int v = 0; v < R; ++v) {
+        const u32 I = I0 | ((u32)v << lo);
+        u64 val;
+        if constexpr (from_hbm) {
+          val = in_range(a, t, I) ? a.src[gaddr(a, t, I)] : 0;
+          if constexpr (COL && FLAG && MODE == MODE_INV) val = montmul(val, twist(a, t, I), a.f);
+        } else {
+          val = lds[lds_phys(I)];
+        }
+        x[g * R + v] = val;
+      }
+      // ---- k fused stages ----------------------------------------------------
+#pragma unroll
+      for (int rr = 0; rr < k; ++rr) {
+        // forward walks the stage bits downwards, inverse upwards
+        const int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
+        const int ps = LO + r;  // stage bit inside the transform: span 2^ps
+        const u64 *tab = a.stage_tw + ((1u << ps) - 1u);
+#pragma unroll
+        for (int v = 0; v < R; ++v) {
+          if (v & (1 << r)) continue;
+          const u32 vlow = (u32)v & ((1u << r) - 1u);
+          const u32 j = ((vlow << lo) | s_low) >> F0;
+          const bool trivial = (LO == 0) && (vlow == 0);  // omega^0, known at compile time
+          u64 &x0 = x[g * R + v], &x1 = x[g * R + v + (1 << r)];
+          if constexpr (MODE == MODE_FWD) {
+            if (trivial)
+              butterfly_fwd(x0, x1, a.f);
+            else
+              butterfly_fwd(x0, x1, tab[j], a.f);
+          } else {
+            if (!COL && FLAG && ps == LOGL - 1) {
+              // fold 1/L into the top stage: (c*x0) +- (c*w)*x1, table holds c*w
+              x0 = montmul(x0, a.scale, a.f);
+              butterfly_inv(x0, x1, tab[j], a.f);
+            } else if (trivial) {
+              butterfly_inv(x0, x1, a.f);
+            } else {
+              butterfly_inv(x0, x1, tab[j], a.f);
+            }
+          }
+        }
+      }
+      // ---- scatter -----------------------------------------------------------
+#pragma unroll
+      for (int v = 0; v < R; ++v) {
+        const u32 I = I0 | ((u32)v << lo);
+        u64 val = x[g * R + v];
+        if constexpr (to_hbm) {
+          if constexpr (COL && FLAG && MODE == MODE_FWD) val = montmul(val, twist(a, t, I), a.f);
+          if (in_range(a, t, I)) a.dst[gaddr(a, t, I)] = val;
+        } else {
+          lds[lds_phys(I)] = val;
+        }
+      }
+    }
+  }
+};
+
+}  // namespace sventt_hip

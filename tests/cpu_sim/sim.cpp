@@ -1,0 +1,128 @@
+// tests/cpu_sim/sim.cpp -- sequential host replay of the plan's passes.
+//
+// TEST-ONLY.  Compiles the very same tile code (sve_ntt_amd/csrc/tile_ntt.h) and
+// planner (plan_core.h) for the host and replays them one workgroup, one step,
+// one thread at a time, so that index arithmetic, twiddle tables and the plan
+// split can be checked against the oracle in the no-GPU test tier.  It is not a
+// fallback: nothing in sve_ntt_amd/ links or loads it, and it is orders of
+// magnitude too slow to be one.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../sve_ntt_amd/csrc/plan_core.h"
+
+using namespace sventt_hip;
+
+namespace {
+
+template <class TN, int IDX> void sim_steps(const PassArgs &a, const typename TN::Tile &t, u64 *lds) {
+  constexpr int SI = (TN::MODE == MODE_FWD) ? IDX : TN::NSTEPS - 1 - IDX;
+  // a barrier separates steps on the GPU; here each step simply runs for all threads
+  for (u32 tid = 0; tid < (u32)TN::NT; ++tid) TN::template step<SI>(a, t, tid, lds);
+  if constexpr (IDX + 1 < TN::NSTEPS) sim_steps<TN, IDX + 1>(a, t, lds);
+}
+
+template <class TN> struct SimLauncher {
+  static int launch(const PassArgs &a, u32 grid, int /*stream*/) {
+    std::vector<u64> lds((size_t)1 << TN::LOGT);
+    // In-place passes: a tile only ever touches its own elements, so replaying the
+    // workgroups one after another is equivalent to running them concurrently.
+    for (u32 b = 0; b < grid; ++b) {
+      const typename TN::Tile t = TN::locate(a, b);
+      if (!t.live) continue;
+      sim_steps<TN, 0>(a, t, lds.data());
+    }
+    return 0;
+  }
+};
+
+using SimEntry = KernelEntryT<int, int>;
+
+thread_local std::string g_err;
+
+int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src) {
+  const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
+  if (pl.n == 1) {
+    if (dst != src) memcpy(dst, src, pl.total * sizeof(u64));
+    return 0;
+  }
+  const u64 *in = src;
+  for (const HostPass &h : passes) {
+    const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
+        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0);
+    if (!e || e->f0 != h.f0 || e->logt != h.logt) {
+      g_err = "registry mismatch";
+      return PLAN_ERR_LOGIC;
+    }
+    const PassArgs a = make_args(pl, h, dst, in, h.stage.data(), h.twist_lo.data(), h.twist_hi.data());
+    e->launch(a, (u32)h.grid, 0);
+    in = dst;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sim_last_error(void) { return g_err.c_str(); }
+
+// Whole transform through the planner (same arguments as sventt_plan_create + forward/inverse).
+int sim_transform(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch, int inverse,
+                  uint64_t *dst, const uint64_t *src) {
+  HostPlan pl;
+  int rc = build_plan(pl, p, g, n, n0_log2, batch, inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  return run_plan(pl, inverse != 0, dst, src);
+}
+
+// One rank's column pass of the sharded six-step, in place on its slab.
+int sim_sharded_columns(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank, int nranks,
+                        int inverse, uint64_t *local) {
+  HostPlan pl;
+  int rc = build_sharded_plan(pl, p, g, n, r_log2, rank, nranks,
+                              inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  return run_plan(pl, inverse != 0, local, local);
+}
+
+// Planner introspection: writes up to `cap` entries of (kind, logl, f0, logt, grid) per pass.
+int sim_plan_shape(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch, int inverse,
+                   int64_t *out, int cap) {
+  HostPlan pl;
+  int rc = build_plan(pl, p, g, n, n0_log2, batch, inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
+  int k = 0;
+  for (const HostPass &h : passes) {
+    if (k >= cap) break;
+    out[5 * k + 0] = h.kind;
+    out[5 * k + 1] = h.logl;
+    out[5 * k + 2] = h.f0;
+    out[5 * k + 3] = h.logt;
+    out[5 * k + 4] = (int64_t)h.grid;
+    ++k;
+  }
+  return k;
+}
+
+// Device-function restatements exposed for unit tests (host build of field64.h).
+uint64_t sim_montmul(uint64_t a, uint64_t w, uint64_t N) {
+  Field f{N, h_montgomery_inverse(N)};
+  return montmul(a, w, f);
+}
+uint64_t sim_addmod(uint64_t a, uint64_t b, uint64_t N) {
+  Field f{N, 0};
+  return addmod(a, b, f);
+}
+uint64_t sim_submod(uint64_t a, uint64_t b, uint64_t N) {
+  Field f{N, 0};
+  return submod(a, b, f);
+}
+uint64_t sim_montgomery_inverse(uint64_t N) { return h_montgomery_inverse(N); }
+uint64_t sim_to_montgomery(uint64_t a, uint64_t N) { return h_to_montgomery(a, N); }
+uint32_t sim_lds_phys(uint32_t I) { return lds_phys(I); }
+
+}  // extern "C"

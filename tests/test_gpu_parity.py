@@ -1,0 +1,261 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the
+golden vectors the real reference produced.  Bit-exact (integer work).
+
+Mirrors the reference's integration test, tests/bench-ntt.cpp:17-65: fill the
+destination with 0x55.., transform out of place, compare every element with
+NTTReference.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+P, G = oracle.BASELINE_P, oracle.BASELINE_G
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    import sve_ntt_amd
+    return sve_ntt_amd
+
+
+def dev(a: np.ndarray):
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def host(t) -> np.ndarray:
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _h(lst):
+    return np.array([int(x, 16) for x in lst], dtype=np.uint64)
+
+
+def run_forward(eng, src, n, batch=1, n0_log2=0, N=P, g=G, in_place=False):
+    ntt = eng.NTT(eng.Modulus(N, g), n, n0_log2=n0_log2, batch=batch, enable_inverse=False)
+    s = dev(src)
+    if in_place:
+        ntt.compute_forward(s)
+        return host(s)
+    d = torch.full_like(s, 0x5555555555555555)  # tests/bench-ntt.cpp:34
+    ntt.compute_forward(d, s)
+    assert np.array_equal(host(s), src), "source was modified by an out-of-place transform"
+    return host(d)
+
+
+def run_inverse(eng, src, n, batch=1, n0_log2=0, N=P, g=G, in_place=False):
+    ntt = eng.NTT(eng.Modulus(N, g), n, n0_log2=n0_log2, batch=batch, enable_forward=False)
+    s = dev(src)
+    if in_place:
+        ntt.compute_inverse(s)
+        return host(s)
+    d = torch.full_like(s, 0x5555555555555555)
+    ntt.compute_inverse(d, s)
+    return host(d)
+
+
+def test_golden_full_vectors(eng, golden_full):
+    """Every full vector the reference generated (all three primes, edge inputs)."""
+    for c in golden_full:
+        N, g, m = int(c["N"], 16), c["g"], 1 << c["log2m"]
+        src = _h(c["src"])
+        assert np.array_equal(run_forward(eng, src, m, N=N, g=g), _h(c["forward"])), (c["prime"], m, c["input"])
+        assert np.array_equal(run_inverse(eng, src, m, N=N, g=g), _h(c["inverse"])), (c["prime"], m, c["input"])
+
+
+@pytest.mark.parametrize("log2m", range(1, 21))
+def test_every_length_vs_oracle(eng, port, log2m):
+    m = 1 << log2m
+    src = port.fill_splitmix(m, 1000 + log2m, P)
+    want = port.forward(src, P, G)
+    assert np.array_equal(run_forward(eng, src, m), want)
+    assert np.array_equal(run_forward(eng, src, m, in_place=True), want)
+    assert np.array_equal(run_inverse(eng, want, m), src)
+    assert np.array_equal(run_inverse(eng, want, m, in_place=True), src)
+    # the oracle's own inverse on arbitrary (not-a-spectrum) input
+    assert np.array_equal(run_inverse(eng, src, m), port.inverse(src, P, G))
+
+
+def test_golden_digests(eng, port, golden_digests):
+    """Large fixtures: recipe -> transform -> digest (incl. BASELINE's 2^24)."""
+    for c in golden_digests:
+        N, g, m = int(c["N"], 16), c["g"], 1 << c["log2m"]
+        if c["input"]["kind"] == "iota":
+            src = port.fill_iota(m, int(c["input"]["start"], 16))
+        else:
+            src = port.fill_splitmix(m, c["input"]["seed"], N)
+        fwd = run_forward(eng, src, m, N=N, g=g)
+        assert [f"{x:016x}" for x in port.digest(fwd)] == c["forward_digest"], (c["prime"], c["log2m"])
+        assert [f"{int(x):016x}" for x in fwd[:8]] == c["forward_head"]
+        if "inverse_digest" in c:
+            inv = run_inverse(eng, src, m, N=N, g=g)
+            assert [f"{x:016x}" for x in port.digest(inv)] == c["inverse_digest"]
+
+
+def test_readme_config_2p17_as_2p8_x_2p9(eng, port):
+    """BASELINE config #2 / README.md:30-32 of the reference: n0 = 2^8, n1 = 2^9."""
+    m = 1 << 17
+    src = port.fill_iota(m, oracle.INPUT_I1_START)
+    ntt = eng.NTT(eng.Modulus(P, G), m, n0_log2=8)
+    assert "col 2^8" in ntt.describe() and "row 2^9" in ntt.describe()
+    want = port.forward(src, P, G)
+    buf = dev(src)
+    ntt.compute_forward(buf)  # in place, as README.md:81
+    assert np.array_equal(host(buf), want)
+    ntt.compute_inverse(buf)
+    assert np.array_equal(host(buf), src)
+
+
+@pytest.mark.parametrize("log2m,n0", [(14, 1), (14, 5), (16, 3), (16, 8), (18, 7), (20, 9),
+                                      (20, 11), (22, 10), (23, 11), (24, 11)])
+def test_explicit_splits(eng, port, log2m, n0):
+    m = 1 << log2m
+    src = port.fill_splitmix(m, 5 * log2m + n0, P)
+    want = port.forward(src, P, G)
+    assert np.array_equal(run_forward(eng, src, m, n0_log2=n0), want)
+    assert np.array_equal(run_inverse(eng, want, m, n0_log2=n0), src)
+
+
+def test_full_size_2p24_roundtrip_and_oracle(eng, port):
+    """BASELINE config #3: N = 2^24 forward + inverse round trip, forward == oracle."""
+    m = 1 << 24
+    src = port.fill_splitmix(m, 42, P)
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    s = dev(src)
+    d = torch.full_like(s, 0x5555555555555555)
+    ntt.compute_forward(d, s)
+    fwd = host(d)
+    assert np.array_equal(fwd, port.forward(src, P, G))
+    # closed forms of tests/test-ntt-reference.cpp:45-63
+    total = (int((src >> np.uint64(32)).sum(dtype=np.uint64)) << 32) + int(
+        (src & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+    assert int(fwd[0]) == total % P
+    ntt.compute_inverse(d)
+    assert np.array_equal(host(d), src)
+
+
+@pytest.mark.parametrize("log2m", [25, 26])
+def test_three_pass_sizes_properties(eng, port, log2m):
+    """Beyond two passes: size-independent checks (closed forms + round trip + linearity)."""
+    m = 1 << log2m
+    rng = np.random.default_rng(log2m)
+    a = rng.integers(0, P, size=m, dtype=np.uint64)
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    assert ntt.num_passes() == 3
+    da = dev(a)
+    fa = torch.empty_like(da)
+    ntt.compute_forward(fa, da)
+    f = host(fa)
+    def isum(v):  # exact integer sum of a uint64 vector (< 2^32 terms)
+        return (int((v >> np.uint64(32)).sum(dtype=np.uint64)) << 32) + int(
+            (v & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+
+    assert int(f[0]) == isum(a) % P
+    assert int(f[1]) == (isum(a[0::2]) - isum(a[1::2])) % P
+    ntt.compute_inverse(fa)
+    assert np.array_equal(host(fa), a)
+
+
+def test_batched_2p12_sampled(eng, port):
+    """BASELINE config #4 at reduced batch: 2^10 independent N = 2^12 transforms in place;
+    every batch checked against the oracle."""
+    m, batch = 1 << 12, 1 << 10
+    src = port.fill_splitmix(m * batch, 7, P)
+    got = run_forward(eng, src, m, batch=batch, in_place=True)
+    for b in range(batch):
+        assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G)), b
+    back = run_inverse(eng, got, m, batch=batch)
+    assert np.array_equal(back, src)
+
+
+@pytest.mark.parametrize("m,batch", [(2, 3), (8, 5), (16, 257), (64, 33), (1 << 9, 7), (1 << 13, 3),
+                                     (1 << 15, 3), (1 << 17, 2)])
+def test_ragged_batches(eng, port, m, batch):
+    """Batch counts that do not fill the last tile (masking) and multi-pass batches."""
+    src = port.fill_splitmix(m * batch, m + batch, P)
+    got = run_forward(eng, src, m, batch=batch)
+    for b in range(batch):
+        assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G))
+    assert np.array_equal(run_inverse(eng, got, m, batch=batch), src)
+
+
+@pytest.mark.parametrize("N,g", [(oracle.TEST62_P, 3), (oracle.GOLDILOCKS_P, 7),
+                                 (0x0C40000000000001, 5), (0x0003F00000000001, 11)])
+def test_other_moduli(eng, port, N, g):
+    """The reference's test primes (tests/ntt-tests/*.hpp:4-5, test-ntt-reference.cpp:17-23)."""
+    for log2m in (3, 10, 13, 15, 18):
+        m = 1 << log2m
+        src = port.fill_splitmix(m, log2m, N)
+        want = port.forward(src, N, g)
+        assert np.array_equal(run_forward(eng, src, m, N=N, g=g), want)
+        assert np.array_equal(run_inverse(eng, want, m, N=N, g=g), src)
+
+
+def test_edge_values(eng, port):
+    for m in (2, 16, 1 << 12, 1 << 16):
+        for src in (np.zeros(m, dtype=np.uint64), np.full(m, P - 1, dtype=np.uint64),
+                    np.where(np.arange(m) % 2 == 0, P - 1, 1).astype(np.uint64)):
+            want = port.forward(src, P, G)
+            assert np.array_equal(run_forward(eng, src, m), want)
+            assert np.array_equal(run_inverse(eng, want, m), src)
+
+
+def test_length_one_and_host_pointers(eng, port):
+    one = np.array([12345], dtype=np.uint64)
+    assert np.array_equal(run_forward(eng, one, 1), one)
+    # host (numpy) buffers are staged through the device, like NTT::compute_* on PageMemory
+    m = 1 << 14
+    src = port.fill_splitmix(m, 3, P)
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    dst = np.full(m, 0x5555555555555555, dtype=np.uint64)
+    ntt.compute_forward(dst, src)
+    assert np.array_equal(dst, port.forward(src, P, G))
+    ntt.compute_inverse(dst)
+    assert np.array_equal(dst, src)
+
+
+def test_linearity_and_convolution(eng, port):
+    """forward(a)+forward(b) == forward(a+b); forward -> pointwise -> inverse is the cyclic
+    convolution (the only caller of the reference does exactly this,
+    examples/magic-series/gaussian-polynomial.hpp:196-241)."""
+    m = 1 << 16
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, P, size=m, dtype=np.uint64)
+    b = np.zeros(m, dtype=np.uint64)
+    b[:5] = [3, 0, 7, 1, P - 2]
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    fa, fb = dev(a), dev(b)
+    ntt.compute_forward(fa)
+    ntt.compute_forward(fb)
+    ab = (a.astype(object) + b.astype(object)) % P
+    fab = dev(np.array(ab, dtype=np.uint64))
+    ntt.compute_forward(fab)
+    s = (host(fa).astype(object) + host(fb).astype(object)) % P
+    assert np.array_equal(host(fab), np.array(s, dtype=np.uint64))
+    prod = torch.empty_like(fa)
+    ntt.pointwise_multiply(prod, fa, fb)
+    ntt.compute_inverse(prod)
+    got = host(prod)
+    ao = a.astype(object)
+    for k in (0, 1, 4, 77, m - 1):
+        want = sum(int(b[j]) * int(ao[(k - j) % m]) for j in range(5)) % P
+        assert int(got[k]) == want
+
+
+def test_error_behaviour(eng):
+    with pytest.raises(ValueError):  # std::invalid_argument
+        eng.NTT(eng.Modulus(P, G), 12)
+    with pytest.raises(ValueError):
+        eng.NTT(eng.Modulus(P, G), 1 << 32)  # 2-adicity of p is 31
+    with pytest.raises(ValueError):
+        eng.NTT(eng.Modulus(P, G), 1 << 10, n0_log2=10)
+    fwd_only = eng.NTT(eng.Modulus(P, G), 1 << 10, enable_inverse=False)
+    x = torch.zeros(1 << 10, dtype=torch.int64, device="cuda")
+    with pytest.raises(eng.SventtError):  # std::logic_error
+        fwd_only.compute_inverse(x)
