@@ -98,25 +98,39 @@ int sventt_run_pass(const sventt_plan *plan, int inverse, int pass_index,
 
 /*
  * Sharded six-step (no precedent in the reference, which is
- * single-node shared memory): the global transform has n = R*C points viewed
- * as R rows x C columns (row-major).  Rank r of `nranks` owns the column block
- * [r*C/nranks, (r+1)*C/nranks) before the exchange and the row block
- * [r*R/nranks, (r+1)*R/nranks) after it.
- *
- * sventt_sharded_columns: `local` is the rank's R x (C/nranks) slab (row-major,
- * leading dimension C/nranks); runs the C/nranks column transforms of length R
- * in place and applies the six-step twiddle omega_n^(bitrev_R(j)*c) with the
- * GLOBAL column index c (layer/sve/generic.hpp:95-105).  The caller then
- * exchanges tiles (RCCL all-to-all) so that each rank holds R/nranks full rows,
- * and finishes with an ordinary batched plan of length C.
- * Inverse = the mirror (rows first, exchange, then this with inverse != 0,
- * which also applies the 1/n scaling).
+ * single-node shared memory).  The global transform has n = R*C points viewed
+ * as R rows x C columns (row-major, R = 2^r_log2).  With Cl = C/nranks and
+ * Rl = R/nranks, rank k owns
+ *   before the exchange: the column block [k*Cl, (k+1)*Cl) as an R x Cl slab
+ *                        (row-major, leading dimension Cl);
+ *   after the exchange:  the rows [k*Rl, (k+1)*Rl), i.e. the contiguous slice
+ *                        [k*n/nranks, (k+1)*n/nranks) of the bit-reversed result.
+ * Forward on every rank:
+ *   1. sventt_sharded_columns(cols, 0, work, slab): the Cl column transforms of
+ *      length R and the six-step twiddle omega_n^(bitrev_R(j)*c) with the GLOBAL
+ *      column index c (layer/sve/generic.hpp:95-105 of the reference);
+ *   2. all-to-all (RCCL): chunk h of `work` (rows [h*Rl,(h+1)*Rl), contiguous)
+ *      goes to rank h; the receive buffer is recv[s][q][c] (source rank s, local
+ *      row q, column c < Cl);
+ *   3. the passes of the ROWS plan, sventt_run_pass(rows, 0, i, ...): pass 0
+ *      reads `recv` and writes whole rows to `out` (it is the first, length-nranks,
+ *      column pass of the length-C row transform and gathers the pieces on the
+ *      fly -- no separate transposition), the remaining passes run in place on
+ *      `out`.
+ * Inverse = the mirror: rows passes 0..k-2 in place on the rows buffer, the last
+ * rows pass writes piece layout, all-to-all back, then
+ * sventt_sharded_columns(cols, 1, ...) which also applies the 1/n scaling.
+ * Both plans take device pointers only and run through the entry points named
+ * here (sventt_forward/inverse refuse them).
  */
 int sventt_sharded_plan_create(uint64_t p, uint64_t g, uint64_t n,
                                uint32_t r_log2, int rank, int nranks,
                                uint32_t flags, sventt_plan **plan);
+int sventt_sharded_rows_plan_create(uint64_t p, uint64_t g, uint64_t n,
+                                    uint32_t r_log2, int rank, int nranks,
+                                    uint32_t flags, sventt_plan **plan);
 int sventt_sharded_columns(const sventt_plan *plan, int inverse,
-                           uint64_t *local, void *stream);
+                           uint64_t *dst, const uint64_t *src, void *stream);
 
 /* Introspection (get_m(): wrapper.hpp:48; modulus_type: wrapper.hpp:32). */
 uint64_t sventt_plan_n(const sventt_plan *plan);

@@ -24,7 +24,7 @@ from dataclasses import dataclass
 from . import _lib
 from ._lib import SventtError  # noqa: F401
 
-__all__ = ["Modulus", "NTT", "ShardedColumns", "SventtError", "BASELINE_MODULUS"]
+__all__ = ["Modulus", "NTT", "SventtError", "BASELINE_MODULUS"]
 
 
 @dataclass(frozen=True)
@@ -174,31 +174,3 @@ class NTT:
         _lib.check(self._lib.sventt_pointwise_multiply(self._h, d, pa, pb, count,
                                                        _stream_handle(stream)))
         return dst
-
-
-class ShardedColumns:
-    """Column pass of the sharded six-step for one rank (include/sventt_hip.h)."""
-
-    def __init__(self, modulus: Modulus, n: int, r_log2: int, rank: int, nranks: int,
-                 enable_forward: bool = True, enable_inverse: bool = True):
-        self._lib = _lib.load()
-        flags = (_lib.SVENTT_FORWARD if enable_forward else 0) | (
-            _lib.SVENTT_INVERSE if enable_inverse else 0)
-        h = ctypes.c_void_p()
-        _lib.check(self._lib.sventt_sharded_plan_create(modulus.modulus, modulus.generator, n,
-                                                        r_log2, rank, nranks, flags,
-                                                        ctypes.byref(h)))
-        self._h = h
-        self.local_elems = (n // nranks)
-
-    def __del__(self):
-        h = getattr(self, "_h", None)
-        if h is not None and h.value:
-            self._lib.sventt_plan_destroy(h)
-            self._h = None
-
-    def run(self, local, inverse: bool = False, stream=None):
-        d, _keep = _buffer(local, self.local_elems)
-        _lib.check(self._lib.sventt_sharded_columns(self._h, int(inverse), d,
-                                                    _stream_handle(stream)))
-        return local

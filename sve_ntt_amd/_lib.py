@@ -36,7 +36,9 @@ SYMBOLS = {
     "sventt_run_pass": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "sventt_sharded_plan_create": (_int, [_u64, _u64, _u64, _u32, _int, _int, _u32,
                                           ctypes.POINTER(_vp)]),
-    "sventt_sharded_columns": (_int, [_vp, _int, _vp, _vp]),
+    "sventt_sharded_rows_plan_create": (_int, [_u64, _u64, _u64, _u32, _int, _int, _u32,
+                                               ctypes.POINTER(_vp)]),
+    "sventt_sharded_columns": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sventt_plan_n": (_u64, [_vp]),
     "sventt_plan_batch": (_u64, [_vp]),
     "sventt_plan_modulus": (_u64, [_vp]),

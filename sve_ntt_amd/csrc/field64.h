@@ -38,9 +38,40 @@ typedef uint32_t u32;
 struct Field {
   u64 N;     // modulus (odd prime, up to 64 bits)
   u64 Ninv;  // N^{-1} mod 2^64   (Modulus::get_montgomery_inverse, modulus.hpp:36-68)
+  u64 negN;  // 2^64 - N
 };
 
 F64_HD u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+
+// 64-bit add / subtract returning the carry / borrow.  On the device these are
+// written with the multiprecision builtins so that the carry comes out of the
+// v_add_co/v_addc_co (v_sub_co/v_subb_co) pair itself instead of a separate
+// 64-bit compare.
+F64_HD bool add64_carry(u64 a, u64 b, u64 &d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 c0, c1;
+  const u32 lo = __builtin_addc((u32)a, (u32)b, 0u, &c0);
+  const u32 hi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+  d = ((u64)hi << 32) | lo;
+  return c1 != 0;
+#else
+  d = a + b;
+  return d < a;
+#endif
+}
+
+F64_HD bool sub64_borrow(u64 a, u64 b, u64 &d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 c0, c1;
+  const u32 lo = __builtin_subc((u32)a, (u32)b, 0u, &c0);
+  const u32 hi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+  d = ((u64)hi << 32) | lo;
+  return c1 != 0;
+#else
+  d = a - b;
+  return a < b;
+#endif
+}
 
 // hi:lo = a*b through 32-bit limbs (maps onto four v_mad_u64_u32).
 F64_HD void mul64x64(u64 a, u64 b, u64 &hi, u64 &lo) {
@@ -70,20 +101,24 @@ F64_HD u64 montmul(u64 a, u64 w, const Field &f) {
   const u32 q0 = (u32)r0;
   const u32 q1 = (u32)(r0 >> 32) + t0 * ni1 + t1 * ni0;
   const u64 g = mulhi64(((u64)q1 << 32) | q0, f.N);
-  const u64 c = thi - g;
-  return (thi < g) ? c + f.N : c;
+  u64 c;
+  const bool borrow = sub64_borrow(thi, g, c);
+  return c + (borrow ? f.N : 0);
 }
 
 // PAdic64SVE::add, 64-bit-N branch (p-adic-64.hpp:40-50): canonical sum.
+// a + b >= N  <=>  a + (b - N mod 2^64) carries out of 64 bits.
 F64_HD u64 addmod(u64 a, u64 b, const Field &f) {
-  const u64 s = a + b;
-  return (s < a || s >= f.N) ? s - f.N : s;
+  u64 e;
+  const bool wrapped = add64_carry(a, b + f.negN, e);
+  return e + (wrapped ? 0 : f.N);
 }
 
 // PAdic64SVE::subtract (p-adic-64.hpp:52-62): canonical difference.
 F64_HD u64 submod(u64 a, u64 b, const Field &f) {
-  const u64 d = a - b;
-  return (a < b) ? d + f.N : d;
+  u64 d;
+  const bool borrow = sub64_borrow(a, b, d);
+  return d + (borrow ? f.N : 0);
 }
 
 // Gentleman-Sande butterfly, PAdic64SVE::butterfly_forward (p-adic-64.hpp:142-178):

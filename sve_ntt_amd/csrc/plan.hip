@@ -70,7 +70,7 @@ int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
   for (size_t i = 0; i < host.size(); ++i) {
     const HostPass &h = host[i];
     DevicePass &d = dev[i];
-    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0);
+    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
     if (!d.kernel) return fail(SVENTT_ERR_LOGIC, "no kernel instantiated for this pass shape");
     if (d.kernel->f0 != h.f0 || d.kernel->logt != h.logt)
       return fail(SVENTT_ERR_LOGIC, "planner and kernel registry disagree on the tile shape");
@@ -233,12 +233,30 @@ int sventt_run_pass(const sventt_plan *pl, int inverse, int pass_index, uint64_t
   return run_pass(pl, inverse != 0, (size_t)pass_index, dst, src, static_cast<hipStream_t>(stream));
 }
 
-int sventt_sharded_columns(const sventt_plan *pl, int inverse, uint64_t *local, void *stream) {
-  if (!pl || !local) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
-  if (!pl->host.sharded) return fail(SVENTT_ERR_LOGIC, "not a sharded plan");
+int sventt_sharded_rows_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank,
+                                    int nranks, uint32_t flags, sventt_plan **out) {
+  if (!out) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null plan pointer");
+  *out = nullptr;
+  sventt_plan *pl = new (std::nothrow) sventt_plan;
+  if (!pl) return fail(SVENTT_ERR_ALLOC, "out of host memory");
+  std::string err;
+  int rc = build_sharded_rows_plan(pl->host, p, g, n, r_log2, rank, nranks, flags, err);
+  pl->host.sharded = true;  // driven pass by pass, never through sventt_forward/inverse
+  if (!rc && check_device()) {
+    delete pl;
+    return SVENTT_ERR_NO_DEVICE;
+  }
+  return finish_plan(pl, rc, err, out);
+}
+
+int sventt_sharded_columns(const sventt_plan *pl, int inverse, uint64_t *dst, const uint64_t *src,
+                           void *stream) {
+  if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!pl->host.sharded || pl->host.local_cols == 0)
+    return fail(SVENTT_ERR_LOGIC, "not a sharded column plan");
   if ((inverse ? pl->inv : pl->fwd).empty())
     return fail(SVENTT_ERR_LOGIC, "direction not enabled in this plan");
-  return run_pass(pl, inverse != 0, 0, local, local, static_cast<hipStream_t>(stream));
+  return run_pass(pl, inverse != 0, 0, dst, src, static_cast<hipStream_t>(stream));
 }
 
 uint64_t sventt_plan_n(const sventt_plan *pl) { return pl ? pl->host.n : 0; }

@@ -30,6 +30,8 @@ struct HostPass {
   bool inverse = false, flag = false;
   u64 istride = 1;  // COL: S
   u64 block = 0;    // COL: M = L*S
+  // gather/scatter passes of the sharded transform address the two sides differently
+  u64 dst_istride = 0, dst_ostride = 0, src_istride = 0, src_ostride = 0;
   u64 grid = 0;
   int f0 = 0, logt = 0;
   std::vector<u64> stage, twist_lo, twist_hi;
@@ -116,6 +118,8 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
   ps.flag = flag;
   ps.istride = S;
   ps.block = S << logl;
+  ps.dst_istride = ps.src_istride = S;
+  ps.dst_ostride = ps.src_ostride = ps.block;
   ps.twist_col_offset = col_offset;
   const bool fold_row_scale = (kind == KIND_ROW) && inverse && flag;
   ps.stage = build_stage_table(f, pl.g, logl, inverse, fold_row_scale ? scale_plain : 1);
@@ -128,13 +132,15 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
     }
     build_twist_tables(f, pl.g, twist_order_log2, inverse, inverse ? scale_plain : 1, ps.twist_lo,
                        ps.twist_hi, ps.twist_shift);
-    ps.f0 = registry_col_f0(logl);
-    ps.logt = ps.f0 + logl;
-    const u64 T = 1ull << ps.f0;
-    if (S % T != 0) {
-      err = "column count is not a multiple of the tile width";
+    ps.f0 = registry_col_f0(logl, ilog2_u64(S));
+    if (ps.f0 < 0 || !is_pow2(S)) {
+      // the reference rejects shapes its blocks do not divide the same way
+      // (layer/sve/blocked-generic.hpp:111-116)
+      err = "too few columns for a column pass of this length";
       return PLAN_ERR_INVALID_ARGUMENT;
     }
+    ps.logt = ps.f0 + logl;
+    const u64 T = 1ull << ps.f0;
     tiles = (pl.total / ps.block) * (S / T);
   } else {
     if (logl > MAX_ROW_LOGL) {
@@ -218,6 +224,7 @@ inline int validate_field(u64 p, u64 g, u64 n, std::string &err) {
 inline void init_field(HostPlan &pl, u64 p, u64 g) {
   pl.f.N = p;
   pl.f.Ninv = h_montgomery_inverse(p);
+  pl.f.negN = 0 - p;
   pl.g = g;
   pl.r2 = h_to_montgomery(h_to_montgomery(1, p), p);
 }
@@ -330,6 +337,81 @@ inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int
   return PLAN_OK;
 }
 
+// Row phase of the sharded six-step on one rank (include/sventt_hip.h): the rank
+// owns R/nranks rows of length C = nranks * Cl, delivered by the all-to-all as
+// nranks pieces per row: piece s of local row q sits at recv[s][q][0..Cl).
+// Forward = COL(nranks, S = Cl) reading that layout and writing whole rows,
+// then the ordinary passes of a length-Cl transform over the R/nranks * nranks
+// runs.  Inverse = the mirror, the last pass scattering back into piece layout.
+// Never scales: the 1/n of the inverse rides on the column phase.
+inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int rank,
+                                   int nranks, u32 flags, std::string &err) {
+  int rc = validate_field(p, g, n, err);
+  if (rc) return rc;
+  if (nranks < 2 || rank < 0 || rank >= nranks || !is_pow2((u64)nranks)) {
+    err = "rank/nranks invalid (nranks must be a power of two >= 2)";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const int logn = ilog2_u64(n), logg = ilog2_u64((u64)nranks);
+  if (r_log2 == 0 || (int)r_log2 >= logn || (int)r_log2 > MAX_COL_LOGL || logg > (int)r_log2 ||
+      logg > MAX_COL_LOGL) {
+    err = "r_log2 out of range";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const int logc = logn - (int)r_log2;
+  if (logg >= logc) {
+    err = "rows are shorter than the rank count";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const int logcl = logc - logg;
+  const u64 Cl = 1ull << logcl, C = 1ull << logc, Rl = (1ull << r_log2) >> logg;
+  init_field(pl, p, g);
+  pl.n = C;  // length of the transforms this plan runs
+  pl.batch = Rl;
+  pl.total = Rl * C;
+  pl.flags = flags;
+  pl.rank = rank;
+  pl.nranks = nranks;
+  std::vector<int> cols;
+  int row = 0;
+  if ((rc = choose_split(logcl, 0, cols, row, err))) return rc;
+  if (flags & PLAN_FORWARD) {
+    pl.fwd.emplace_back();
+    HostPass &gp = pl.fwd.back();
+    if ((rc = make_host_pass(pl, gp, KIND_COL, logg, Cl, false, true, 1, 0, logc, err))) return rc;
+    gp.src_istride = Rl * Cl;  // piece s
+    gp.src_ostride = Cl;       // local row q
+    int rem = logcl;
+    for (size_t i = 0; i < cols.size(); ++i) {
+      pl.fwd.emplace_back();
+      rem -= cols[i];
+      if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_COL, cols[i], 1ull << rem, false, true, 1, 0,
+                               rem + cols[i], err)))
+        return rc;
+    }
+    pl.fwd.emplace_back();
+    if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_ROW, row, 1, false, false, 1, 0, 0, err))) return rc;
+  }
+  if (flags & PLAN_INVERSE) {
+    pl.inv.emplace_back();
+    if ((rc = make_host_pass(pl, pl.inv.back(), KIND_ROW, row, 1, true, false, 1, 0, 0, err))) return rc;
+    int rem = row;
+    for (size_t k = cols.size(); k-- > 0;) {
+      pl.inv.emplace_back();
+      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_COL, cols[k], 1ull << rem, true, true, 1, 0,
+                               rem + cols[k], err)))
+        return rc;
+      rem += cols[k];
+    }
+    pl.inv.emplace_back();
+    HostPass &sp = pl.inv.back();
+    if ((rc = make_host_pass(pl, sp, KIND_COL, logg, Cl, true, true, 1, 0, logc, err))) return rc;
+    sp.dst_istride = Rl * Cl;
+    sp.dst_ostride = Cl;
+  }
+  return PLAN_OK;
+}
+
 // Kernel arguments of a pass, given where its tables live.
 inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, const u64 *src,
                           const u64 *stage, const u64 *twist_lo, const u64 *twist_hi) {
@@ -339,8 +421,10 @@ inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, cons
   a.f = pl.f;
   a.stage_tw = stage;
   a.total = pl.total;
-  a.istride = ps.istride;
-  a.ostride = ps.block;
+  a.istride = ps.dst_istride;
+  a.ostride = ps.dst_ostride;
+  a.src_istride = ps.src_istride;
+  a.src_ostride = ps.src_ostride;
   a.tiles_per_outer = (ps.kind == KIND_COL) ? (u32)(ps.istride >> ps.f0) : 0;
   a.twist_lo = twist_lo;
   a.twist_hi = twist_hi;

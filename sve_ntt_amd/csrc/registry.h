@@ -45,6 +45,13 @@ template <int LOGL, int MODE>
 using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
                         typename DefaultSteps<LOGL>::type>;
 
+// Narrow COL tiles (T = 8 whatever the column length) for blocks with fewer
+// columns than the wide tile wants; tiny tiles, only met at small n.
+constexpr int NARROW_F0 = 3;
+template <int LOGL, int MODE>
+using ColTileNarrow = TileNTT<LOGL + NARROW_F0, NARROW_F0, LOGL, REG_LOGE, MODE, true,
+                              typename DefaultSteps<LOGL>::type>;
+
 template <class Status, class Stream> struct KernelEntryT {
   int kind, logl, dir, flag;
   int logt, f0, threads;
@@ -73,9 +80,16 @@ Entry make_entry(int kind, int dir, int flag) {
   make_entry<ColTile<L, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1), \
   make_entry<ColTile<L, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
 
+#define SVENTT_NARROW_ENTRIES(L)                                                  \
+  make_entry<ColTileNarrow<L, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1), \
+  make_entry<ColTileNarrow<L, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
+
 template <class Entry, template <class> class Launcher>
-const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag) {
+const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int f0) {
   static const Entry table[] = {
+      SVENTT_NARROW_ENTRIES(1), SVENTT_NARROW_ENTRIES(2), SVENTT_NARROW_ENTRIES(3),
+      SVENTT_NARROW_ENTRIES(4), SVENTT_NARROW_ENTRIES(5), SVENTT_NARROW_ENTRIES(6),
+      SVENTT_NARROW_ENTRIES(7), SVENTT_NARROW_ENTRIES(8),
       SVENTT_ROW_ENTRIES(1),  SVENTT_ROW_ENTRIES(2),  SVENTT_ROW_ENTRIES(3),
       SVENTT_ROW_ENTRIES(4),  SVENTT_ROW_ENTRIES(5),  SVENTT_ROW_ENTRIES(6),
       SVENTT_ROW_ENTRIES(7),  SVENTT_ROW_ENTRIES(8),  SVENTT_ROW_ENTRIES(9),
@@ -87,12 +101,18 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag) {
       SVENTT_COL_ENTRIES(10), SVENTT_COL_ENTRIES(11),
   };
   for (const Entry &e : table)
-    if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag) return &e;
+    if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0) return &e;
   return nullptr;
 }
 
 // Shape facts the host planner needs without instantiating anything.
-inline int registry_col_f0(int logl) { return col_f0(logl); }
+// log2 of the tile width for a column pass of length 2^logl over 2^logs columns
+// (-1: fewer columns than the narrowest tile).
+inline int registry_col_f0(int logl, int logs) {
+  if (logs >= col_f0(logl)) return col_f0(logl);
+  if (logs >= NARROW_F0 && logl <= 8) return NARROW_F0;
+  return -1;
+}
 inline int registry_row_logt(int logl) { return row_logt(logl); }
 
 }  // namespace sventt_hip

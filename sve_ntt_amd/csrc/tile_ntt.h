@@ -46,10 +46,14 @@ struct PassArgs {
   const u64 *stage_tw;  // stage tables of the pass length L: stage bit p (span 2^p) at
                         // [2^p - 1, 2^(p+1) - 1): omega_{2^(p+1)}^j, Montgomery form
   u64 total;            // elements in the whole array (tiles past it are masked)
-  // COL geometry: element (o, i, c) lives at o*ostride + i*istride + c
+  // COL geometry: element (o, i, c) is read from o*src_ostride + i*src_istride + c and
+  // written to o*ostride + i*istride + c (the two differ only in the gather/scatter
+  // passes next to the all-to-all of the sharded transform)
   u64 istride;
   u64 ostride;
-  u32 tiles_per_outer;  // istride / T
+  u64 src_istride;
+  u64 src_ostride;
+  u32 tiles_per_outer;  // columns / T
   // twist of the pass (six-step twiddle, layer/sve/generic.hpp:95-105,169-188):
   // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
   const u64 *twist_lo;
@@ -103,7 +107,8 @@ struct TileNTT {
   static_assert(!COL || F0 + LOGL == LOGT, "a COL tile holds whole columns");
 
   struct Tile {
-    u64 base;    // element offset of the tile in HBM
+    u64 base;    // element offset of the tile in HBM (destination side)
+    u64 sbase;   // same, source side
     u32 c0;      // COL: first column (index inside the M-point sub-transform)
     bool live;   // false: whole tile lies past the end (ROW, ragged batch)
   };
@@ -114,10 +119,12 @@ struct TileNTT {
       const u32 o = block / a.tiles_per_outer, ct = block - o * a.tiles_per_outer;
       t.c0 = ct * (u32)T;
       t.base = (u64)o * a.ostride + t.c0;
+      t.sbase = (u64)o * a.src_ostride + t.c0;
       t.live = true;
     } else {
       t.c0 = 0;
       t.base = (u64)block << LOGT;
+      t.sbase = t.base;
       t.live = t.base < a.total;
     }
     return t;
@@ -128,6 +135,13 @@ struct TileNTT {
       return t.base + (u64)(I >> F0) * a.istride + (I & (u32)(T - 1));
     else
       return t.base + I;
+  }
+
+  F64_HD static u64 saddr(const PassArgs &a, const Tile &t, u32 I) {
+    if constexpr (COL)
+      return t.sbase + (u64)(I >> F0) * a.src_istride + (I & (u32)(T - 1));
+    else
+      return t.sbase + I;
   }
 
   F64_HD static bool in_range(const PassArgs &a, const Tile &t, u32 I) {
@@ -172,7 +186,7 @@ struct TileNTT {
         const u32 I = I0 | ((u32)v << lo);
         u64 val;
         if constexpr (from_hbm) {
-          val = in_range(a, t, I) ? a.src[gaddr(a, t, I)] : 0;
+          val = in_range(a, t, I) ? a.src[saddr(a, t, I)] : 0;
           if constexpr (COL && FLAG && MODE == MODE_INV) val = montmul(val, twist(a, t, I), a.f);
         } else {
           val = lds[lds_phys(I)];

@@ -51,7 +51,7 @@ int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src) {
   const u64 *in = src;
   for (const HostPass &h : passes) {
     const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0);
+        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
     if (!e || e->f0 != h.f0 || e->logt != h.logt) {
       g_err = "registry mismatch";
       return PLAN_ERR_LOGIC;
@@ -78,14 +78,44 @@ int sim_transform(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t
   return run_plan(pl, inverse != 0, dst, src);
 }
 
-// One rank's column pass of the sharded six-step, in place on its slab.
+// One rank's column pass of the sharded six-step (same arguments as sventt_sharded_columns).
 int sim_sharded_columns(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank, int nranks,
-                        int inverse, uint64_t *local) {
+                        int inverse, uint64_t *dst, const uint64_t *src) {
   HostPlan pl;
   int rc = build_sharded_plan(pl, p, g, n, r_log2, rank, nranks,
                               inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
   if (rc) return rc;
-  return run_plan(pl, inverse != 0, local, local);
+  return run_plan(pl, inverse != 0, dst, src);
+}
+
+// Row phase of the sharded six-step, one pass at a time (sventt_run_pass on the rows plan).
+int sim_sharded_rows_num_passes(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank,
+                                int nranks) {
+  HostPlan pl;
+  int rc = build_sharded_rows_plan(pl, p, g, n, r_log2, rank, nranks, PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  return (int)pl.fwd.size();
+}
+
+int sim_sharded_rows_pass(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank, int nranks,
+                          int inverse, int index, uint64_t *dst, const uint64_t *src) {
+  HostPlan pl;
+  int rc = build_sharded_rows_plan(pl, p, g, n, r_log2, rank, nranks,
+                                   inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
+  if (index < 0 || (size_t)index >= passes.size()) return PLAN_ERR_INVALID_ARGUMENT;
+  const HostPass &h = passes[(size_t)index];
+  const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
+      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
+  if (!e) return PLAN_ERR_LOGIC;
+  if (dst == src && (h.src_istride != h.dst_istride || h.src_ostride != h.dst_ostride)) {
+    g_err = "gather/scatter passes cannot run in place";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const PassArgs a = make_args(pl, h, dst, src, h.stage.data(), h.twist_lo.data(), h.twist_hi.data());
+  e->launch(a, (u32)h.grid, 0);
+  return 0;
 }
 
 // Planner introspection: writes up to `cap` entries of (kind, logl, f0, logt, grid) per pass.
@@ -110,15 +140,15 @@ int sim_plan_shape(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_
 
 // Device-function restatements exposed for unit tests (host build of field64.h).
 uint64_t sim_montmul(uint64_t a, uint64_t w, uint64_t N) {
-  Field f{N, h_montgomery_inverse(N)};
+  Field f{N, h_montgomery_inverse(N), 0 - N};
   return montmul(a, w, f);
 }
 uint64_t sim_addmod(uint64_t a, uint64_t b, uint64_t N) {
-  Field f{N, 0};
+  Field f{N, 0, 0 - N};
   return addmod(a, b, f);
 }
 uint64_t sim_submod(uint64_t a, uint64_t b, uint64_t N) {
-  Field f{N, 0};
+  Field f{N, 0, 0 - N};
   return submod(a, b, f);
 }
 uint64_t sim_montgomery_inverse(uint64_t N) { return h_montgomery_inverse(N); }
