@@ -1,0 +1,124 @@
+// include/sventt/wrapper.hpp -- sventt::NTT<kernel_type> on the GPU engine.
+//
+// Same public surface as the reference's wrapper (include/sventt/wrapper.hpp:
+// 13-83 there): NTT(enable_forward, enable_inverse, allocate_huge_pages),
+// get_m(), modulus_type, compute_forward/compute_inverse(dst[, src]) const.
+// Construction builds the plan through the C ABI (include/sventt_hip.h) instead
+// of filling an SVE twiddle blob; the transforms run in the HIP kernels.
+// Pointers may be host memory (PageMemory, std::vector: staged through the
+// device, the call returns when dst is complete) or device memory (asynchronous
+// on the default stream).  Errors come back as the exception types the reference
+// throws: std::invalid_argument, std::logic_error, std::bad_alloc; anything
+// HIP-specific is a std::runtime_error.
+#ifndef SVENTT_GPU_WRAPPER_HPP_INCLUDED
+#define SVENTT_GPU_WRAPPER_HPP_INCLUDED
+
+#include <bit>
+#include <cstdint>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+#include "sventt_hip.h"
+
+namespace sventt {
+
+namespace detail {
+
+inline void throw_on_error(const int status) {
+  if (status == SVENTT_OK) {
+    return;
+  }
+  const std::string message{sventt_last_error()};
+  switch (status) {
+  case SVENTT_ERR_INVALID_ARGUMENT:
+    throw std::invalid_argument{message};
+  case SVENTT_ERR_ALLOC:
+    throw std::bad_alloc{};
+  case SVENTT_ERR_LOGIC:
+    throw std::logic_error{message};
+  default:
+    throw std::runtime_error{"sventt-hip: " + message};
+  }
+}
+
+} // namespace detail
+
+template <class kernel_type_> class NTT {
+public:
+  using kernel_type = kernel_type_;
+  using modulus_type = typename kernel_type::modulus_type;
+
+private:
+  sventt_plan *plan{};
+
+  // The R of an explicit six-step split, if it is one the engine's column pass
+  // can take (at most 2^11 rows, at least 8 columns); otherwise let it choose.
+  static constexpr std::uint32_t preferred_rows_log2(void) {
+    constexpr std::uint64_t rows{kernel_type::get_six_step_rows()};
+    constexpr std::uint64_t m{kernel_type::get_m()};
+    if (rows < 2 || rows >= m) {
+      return 0;
+    }
+    const std::uint32_t log2_rows{static_cast<std::uint32_t>(std::countr_zero(rows))};
+    const std::uint32_t log2_cols{static_cast<std::uint32_t>(std::countr_zero(m / rows))};
+    const std::uint32_t wide{log2_rows >= 9 ? 3u : 12u - log2_rows};
+    if (log2_rows > 11 || log2_cols > 13 || (log2_cols < wide && (log2_cols < 3 || log2_rows > 8))) {
+      return 0;
+    }
+    return log2_rows;
+  }
+
+public:
+  NTT(const bool enable_forward = true, const bool enable_inverse = true,
+      [[maybe_unused]] const bool allocate_huge_pages = true) {
+    const std::uint32_t flags{(enable_forward ? std::uint32_t{SVENTT_FORWARD} : 0u) |
+                              (enable_inverse ? std::uint32_t{SVENTT_INVERSE} : 0u)};
+    if (flags == 0) {
+      return;  // the reference allows an NTT with neither table; it then cannot transform
+    }
+    detail::throw_on_error(sventt_plan_create(modulus_type::get_modulus(),
+                                              modulus_type::get_generator(), kernel_type::get_m(),
+                                              preferred_rows_log2(), 1, flags, &plan));
+  }
+
+  NTT(const NTT &) = delete;
+  NTT &operator=(const NTT &) = delete;
+  NTT(NTT &&that) noexcept : plan{that.plan} { that.plan = nullptr; }
+  NTT &operator=(NTT &&that) noexcept {
+    if (this != &that) {
+      sventt_plan_destroy(plan);
+      plan = that.plan;
+      that.plan = nullptr;
+    }
+    return *this;
+  }
+  ~NTT(void) { sventt_plan_destroy(plan); }
+
+  static constexpr std::uint64_t get_m(void) { return kernel_type::get_m(); }
+
+  // what the engine made of kernel_type, e.g. "col 2^8 x T16 (stride 512) | row 2^9 (tile 2^12)"
+  std::string describe(void) const { return plan ? sventt_plan_describe(plan) : ""; }
+
+  void compute_forward(std::uint64_t *const dst, const std::uint64_t *const src) const {
+    if (plan == nullptr) {
+      throw std::logic_error{"NTT was constructed with forward and inverse disabled"};
+    }
+    detail::throw_on_error(sventt_forward(plan, dst, src, nullptr));
+  }
+
+  void compute_forward(std::uint64_t *const dst) const { compute_forward(dst, dst); }
+
+  void compute_inverse(std::uint64_t *const dst, const std::uint64_t *const src) const {
+    if (plan == nullptr) {
+      throw std::logic_error{"NTT was constructed with forward and inverse disabled"};
+    }
+    detail::throw_on_error(sventt_inverse(plan, dst, src, nullptr));
+  }
+
+  void compute_inverse(std::uint64_t *const dst) const { compute_inverse(dst, dst); }
+};
+
+} // namespace sventt
+
+#endif /* SVENTT_GPU_WRAPPER_HPP_INCLUDED */

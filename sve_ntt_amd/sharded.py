@@ -102,6 +102,18 @@ class ShardedNTT:
         if events is not None:
             events[i].record()
 
+    def _exchange(self, out, inp):
+        """The one collective of the transform.  RCCL moves device buffers directly;
+        a gloo group (rehearsals on a box with fewer GPUs than ranks) cannot, so the
+        chunks are bounced through host memory there -- transport only, the
+        transforms on either side still run in the HIP kernels."""
+        if inp.is_cuda and self.dist.get_backend() == "gloo":
+            h_in, h_out = inp.cpu(), out.cpu()
+            self.dist.all_to_all_single(h_out, h_in)
+            out.copy_(h_out)
+        else:
+            self.dist.all_to_all_single(out, inp)
+
     def forward(self, dst, src, events=None):
         """natural-order column slab ``src`` -> bit-reversed row block ``dst``."""
         e = self.engine
@@ -109,7 +121,7 @@ class ShardedNTT:
         e.columns(False, self._work, src)
         self._mark(events, 1)
         # chunk h of _work = rows [h*R/G, (h+1)*R/G) of the slab -> rank h
-        self.dist.all_to_all_single(self._recv, self._work)
+        self._exchange(self._recv, self._work)
         self._mark(events, 2)
         for i in range(e.rows_passes):
             e.rows_pass(False, i, dst, self._recv if i == 0 else dst)
@@ -128,7 +140,7 @@ class ShardedNTT:
             self._mark(events, 1 + i)
         e.rows_pass(True, k - 1, self._recv, cur)  # scatters into piece layout
         self._mark(events, k)
-        self.dist.all_to_all_single(self._work, self._recv)
+        self._exchange(self._work, self._recv)
         self._mark(events, k + 1)
         e.columns(True, dst, self._work)
         self._mark(events, k + 2)

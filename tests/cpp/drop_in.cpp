@@ -1,0 +1,207 @@
+// tests/cpp/drop_in.cpp -- "switch the include path and relink" check for the C++ facade.
+//
+// User code written against the reference's template API (kernel_type spelled with
+// Modulus / PAdic64SVE / Radix*SVELayer / IterativeNTT / RecursiveNTT /
+// [Blocked]GenericSVELayer / Transpose..., run through sventt::NTT<kernel_type>)
+// is compiled here against include/sventt/ of THIS repository and linked with
+// libsventt_hip.so.  The harness follows the reference's tests/bench-ntt.cpp:17-65:
+// src[i] = start + i, dst pre-filled with 0x55.., transform out of place, compare
+// every element with the scalar oracle -- here with exact equality, since the
+// engine returns canonical residues.
+//
+// The kernel_type definitions below have the shapes of the reference's own
+// configurations: README.md:13-82 (blocked six-step 2^17 = 2^8 x 2^9, 64-bit
+// prime) and tests/ntt-tests/{iterative-sve-radix8-two12, recursive-sve-radix248-two13,
+// recursive-sve-fourstep-two13}.hpp (62-bit prime).
+//
+//   g++ -std=c++20 -Iinclude tests/cpp/drop_in.cpp -Lsve_ntt_amd -lsventt_hip
+//       -Loracle -lntt_oracle -Wl,-rpath,... -o drop_in && ./drop_in
+//   ./drop_in --compile-only-check   exits 0 without touching the GPU
+#include <sventt/sventt.hpp>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../oracle/ntt_oracle.h"
+
+using namespace sventt;
+
+namespace readme_blocked_six_step {
+using modulus_type = Modulus<UINT64_C(0xfffffc6e80000001), 3>;
+using modmul_type = PAdic64SVE<modulus_type>;
+using transposition_type =
+    TransposeParallelSVEInRegisterExplicitBlockingRowFirst<32, 128, 128 + 32, 3>;
+constexpr std::uint64_t n{std::uint64_t{1} << 17}, n0{std::uint64_t{1} << 8},
+    n1{std::uint64_t{1} << 9};
+using ntt0_type = IterativeNTT<modulus_type, n0, RadixEightSVELayer<modmul_type, n0, n0>,
+                               RadixEightSVELayer<modmul_type, n0, (n0 >> 3)>,
+                               RadixFourSVELayer<modmul_type, n0, (n0 >> 6)>>;
+using ntt1_type =
+    RecursiveNTT<modulus_type, n1, RadixEightSVELayer<modmul_type, n1, n1>,
+                 IterativeNTT<modulus_type, n1, RadixEightSVELayer<modmul_type, n1, (n1 >> 3)>,
+                              RadixEightSVELayer<modmul_type, n1, (n1 >> 6)>>,
+                 false>;
+using kernel_type =
+    RecursiveNTT<modulus_type, n,
+                 BlockedGenericSVELayer<modmul_type, n, ntt0_type, 32, 2, 128, transposition_type>,
+                 ntt1_type, true>;
+} // namespace readme_blocked_six_step
+
+namespace test62 {
+using modulus_type = Modulus<UINT64_C(0x3a00000000000001), 3>;
+using modmul_type = PAdic64SVE<modulus_type>;
+
+constexpr std::uint64_t m12{std::uint64_t{1} << 12};
+using iterative_radix8 =
+    IterativeNTT<modulus_type, m12, RadixEightSVELayer<modmul_type, m12, (m12 >> 0), 1, false>,
+                 RadixEightSVELayer<modmul_type, m12, (m12 >> 3), 1, true>,
+                 RadixEightSVELayer<modmul_type, m12, (m12 >> 6), 1, false>,
+                 RadixEightSVELayer<modmul_type, m12, (m12 >> 9), m12, true>>;
+
+constexpr std::uint64_t m13{std::uint64_t{1} << 13}, m10{std::uint64_t{1} << 10},
+    m9{std::uint64_t{1} << 9};
+using inner9 = IterativeNTT<modulus_type, m9, RadixEightSVELayer<modmul_type, m9, m9, 1, true>,
+                            RadixFourSVELayer<modmul_type, m9, (m9 >> 3), 1, true>,
+                            RadixTwoSVELayer<modmul_type, m9, (m9 >> 5), 1, false>,
+                            RadixEightSVELayer<modmul_type, m9, (m9 >> 6), m13, false>>;
+using inner10 =
+    RecursiveNTT<modulus_type, m10, RadixTwoSVELayer<modmul_type, m10, m10, 1, false>, inner9, false>;
+using recursive_radix248 =
+    RecursiveNTT<modulus_type, m13, RadixEightSVELayer<modmul_type, m13, m13, 1, true>, inner10, false>;
+
+constexpr std::uint64_t m15{std::uint64_t{1} << 15}, m6{std::uint64_t{1} << 6};
+using column9 = IterativeNTT<modulus_type, m9, RadixEightSVELayer<modmul_type, m9, m9>,
+                             RadixFourSVELayer<modmul_type, m9, (m9 >> 3)>,
+                             RadixTwoSVELayer<modmul_type, m9, (m9 >> 5)>,
+                             RadixEightSVELayer<modmul_type, m9, (m9 >> 6), m15>>;
+using row6 = IterativeNTT<modulus_type, m6, RadixEightSVELayer<modmul_type, m6, m6>,
+                          RadixEightSVELayer<modmul_type, m6, (m6 >> 3)>>;
+using four_step =
+    RecursiveNTT<modulus_type, m15,
+                 GenericSVELayer<modmul_type, m15, column9, 8, 2, TransposeParallelSVEInRegister<8, 64>>,
+                 row6, true>;
+} // namespace test62
+
+namespace big {
+// BASELINE config #3 spelled as a six-step 2^24 = 2^11 x 2^13
+using modulus_type = Modulus<UINT64_C(0xfffffc6e80000001), 3>;
+using modmul_type = PAdic64SVE<modulus_type>;
+constexpr std::uint64_t n{std::uint64_t{1} << 24}, r{std::uint64_t{1} << 11}, c{std::uint64_t{1} << 13};
+using col = IterativeNTT<modulus_type, r, RadixEightSVELayer<modmul_type, r, r>,
+                         RadixEightSVELayer<modmul_type, r, (r >> 3)>,
+                         RadixEightSVELayer<modmul_type, r, (r >> 6)>,
+                         RadixFourSVELayer<modmul_type, r, (r >> 9)>>;
+using row = IterativeNTT<modulus_type, c, RadixEightSVELayer<modmul_type, c, c>,
+                         RadixEightSVELayer<modmul_type, c, (c >> 3)>,
+                         RadixEightSVELayer<modmul_type, c, (c >> 6)>,
+                         RadixEightSVELayer<modmul_type, c, (c >> 9)>,
+                         RadixTwoSVELayer<modmul_type, c, (c >> 12)>>;
+using kernel_type =
+    RecursiveNTT<modulus_type, n,
+                 BlockedGenericSVELayer<modmul_type, n, col, 32, 2, 128,
+                                        TransposeParallelSVEInRegister<8, 8>>,
+                 row, true>;
+} // namespace big
+
+template <class kernel_type, bool is_inverse> static bool check(const char *name) {
+  using ntt_type = NTT<kernel_type>;
+  using modulus_type = typename ntt_type::modulus_type;
+  constexpr std::uint64_t N{modulus_type::get_modulus()}, g{modulus_type::get_generator()};
+  const std::uint64_t m{ntt_type::get_m()};
+
+  PageMemory<std::uint64_t> buffer{m * 3, false};
+  std::uint64_t *const src{&buffer[0]}, *const dst{&buffer[m]}, *const ref{&buffer[m * 2]};
+  oracle_fill_iota(src, m, UINT64_C(0x0123456789abcdef) % (N - m));
+  std::memset(dst, 0x55, sizeof(std::uint64_t) * m);
+  std::memset(ref, 0xaa, sizeof(std::uint64_t) * m);
+  if (is_inverse) {
+    oracle_ntt_inverse(ref, src, m, N, g);
+  } else {
+    oracle_ntt_forward(ref, src, m, N, g);
+  }
+
+  const ntt_type ntt{!is_inverse, is_inverse, false};
+  if (is_inverse) {
+    ntt.compute_inverse(dst, src);
+  } else {
+    ntt.compute_forward(dst, src);
+  }
+  for (std::uint64_t i{}; i < m; ++i) {
+    if (dst[i] != ref[i]) {
+      std::printf("MISMATCH %s %s at %llu\n", is_inverse ? "Inverse," : "Forward,", name,
+                  static_cast<unsigned long long>(i));
+      return false;
+    }
+  }
+
+  // the in-place overloads and the round trip
+  const ntt_type both;
+  std::memcpy(dst, src, sizeof(std::uint64_t) * m);
+  both.compute_forward(dst);
+  both.compute_inverse(dst);
+  if (std::memcmp(dst, src, sizeof(std::uint64_t) * m) != 0) {
+    std::printf("MISMATCH round trip %s\n", name);
+    return false;
+  }
+  std::printf("ok %s %s  [%s]\n", is_inverse ? "Inverse," : "Forward,", name, ntt.describe().c_str());
+  return true;
+}
+
+static bool check_errors(void) {
+  using modulus_type = Modulus<UINT64_C(0xfffffc6e80000001), 3>;
+  using modmul_type = PAdic64SVE<modulus_type>;
+  using k = IterativeNTT<modulus_type, 4, RadixFourSVELayer<modmul_type, 4, 4>>;
+  const NTT<k> forward_only{true, false, false};
+  std::uint64_t v[4]{1, 2, 3, 4};
+  try {
+    forward_only.compute_inverse(v);
+  } catch (const std::logic_error &) {
+    try {
+      (void)modulus_type::get_root_forward(7);  // 7 does not divide p-1
+    } catch (const std::invalid_argument &) {
+      std::printf("ok error mapping\n");
+      return true;
+    }
+  }
+  std::printf("MISMATCH error mapping\n");
+  return false;
+}
+
+// compile-time facts the reference's API promises
+static_assert(readme_blocked_six_step::kernel_type::get_m() == (std::uint64_t{1} << 17));
+static_assert(NTT<readme_blocked_six_step::kernel_type>::get_m() == (std::uint64_t{1} << 17));
+static_assert(readme_blocked_six_step::ntt0_type::get_m() == 256);
+static_assert(Modulus<UINT64_C(0xfffffc6e80000001), 3>::get_montgomery_inverse() ==
+              UINT64_C(0x4000039180000001));
+static_assert(Modulus<UINT64_C(0xfffffc6e80000001), 3>::get_root_forward(std::uint64_t{1} << 24) ==
+              UINT64_C(0x3a215e9b536c5fbc));
+static_assert(Modulus<UINT64_C(0xffffffff00000001), 7>::multiply(
+                  Modulus<UINT64_C(0xffffffff00000001), 7>::get_root_forward(257),
+                  Modulus<UINT64_C(0xffffffff00000001), 7>::get_root_inverse(257)) == 1);
+static_assert(PAdic64SVE<Modulus<UINT64_C(0xfffffc6e80000001), 3>>::to_montgomery(1) ==
+              UINT64_C(0x000003917fffffff));
+static_assert(bitreverse(1) == (std::uint64_t{1} << 63));
+
+int main(int argc, char **argv) {
+  if (argc > 1 && std::string{argv[1]} == "--compile-only-check") {
+    std::printf("facade compiled and linked\n");
+    return 0;
+  }
+  bool ok{true};
+  ok &= check<readme_blocked_six_step::kernel_type, false>("README blocked six-step 2^17");
+  ok &= check<readme_blocked_six_step::kernel_type, true>("README blocked six-step 2^17");
+  ok &= check<test62::iterative_radix8, false>("iterative, SVE, radix-8");
+  ok &= check<test62::iterative_radix8, true>("iterative, SVE, radix-8");
+  ok &= check<test62::recursive_radix248, false>("recursive, SVE, radix-2,4,8");
+  ok &= check<test62::recursive_radix248, true>("recursive, SVE, radix-2,4,8");
+  ok &= check<test62::four_step, false>("recursive, SVE, four-step");
+  ok &= check<test62::four_step, true>("recursive, SVE, four-step");
+  ok &= check<big::kernel_type, false>("six-step 2^24 = 2^11 x 2^13");
+  ok &= check_errors();
+  std::printf(ok ? "ALL OK\n" : "FAILED\n");
+  return ok ? 0 : 1;
+}

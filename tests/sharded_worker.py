@@ -26,8 +26,11 @@ def main() -> None:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if engine_kind == "hip":
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group("nccl")
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local % ndev)
+        # RCCL refuses two ranks on one device; on a one-GPU box the exchange goes
+        # over gloo (host bounce) while every transform still runs in the HIP kernels
+        dist.init_process_group("nccl" if ndev >= int(os.environ["WORLD_SIZE"]) else "gloo")
         device = torch.device("cuda", torch.cuda.current_device())
     else:
         dist.init_process_group("gloo")
