@@ -18,6 +18,7 @@
 #pragma once
 
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,23 @@ enum : int {
   PLAN_ERR_LOGIC = -4,
 };
 enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u };
+
+// Tuning knobs (environment, read once).  SVENTT_COL_SLIM=0/1: 4-column instead of
+// 8-column tiles for column passes of length >= 2^10 (two workgroups per CU).
+struct Tuning {
+  bool col_slim;
+  int max_col_logl;
+};
+inline const Tuning &tuning(void) {
+  static const Tuning t = [] {
+    Tuning x;
+    const char *e = std::getenv("SVENTT_COL_SLIM");
+    x.col_slim = e ? (std::atoi(e) != 0) : false;
+    x.max_col_logl = x.col_slim ? 12 : MAX_COL_LOGL;
+    return x;
+  }();
+  return t;
+}
 
 inline bool is_pow2(u64 x) { return x && !(x & (x - 1)); }
 inline int ilog2_u64(u64 x) {
@@ -126,13 +144,13 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
   if (fold_row_scale) ps.scale = h_to_montgomery(scale_plain % f.N, f.N);
   u64 tiles;
   if (kind == KIND_COL) {
-    if (logl > MAX_COL_LOGL) {
+    if (logl > tuning().max_col_logl) {
       err = "column pass longer than one workgroup can hold";
       return PLAN_ERR_LOGIC;
     }
     build_twist_tables(f, pl.g, twist_order_log2, inverse, inverse ? scale_plain : 1, ps.twist_lo,
                        ps.twist_hi, ps.twist_shift);
-    ps.f0 = registry_col_f0(logl, ilog2_u64(S));
+    ps.f0 = registry_col_f0(logl, ilog2_u64(S), tuning().col_slim);
     if (ps.f0 < 0 || !is_pow2(S)) {
       // the reference rejects shapes its blocks do not divide the same way
       // (layer/sve/blocked-generic.hpp:111-116)
@@ -167,7 +185,7 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
   cols.clear();
   int rem = logn;
   if (n0_log2 != 0) {
-    if ((int)n0_log2 >= logn || (int)n0_log2 > MAX_COL_LOGL) {
+    if ((int)n0_log2 >= logn || (int)n0_log2 > tuning().max_col_logl) {
       err = "n0_log2 out of range for this transform length";
       return PLAN_ERR_INVALID_ARGUMENT;
     }
@@ -426,6 +444,7 @@ inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, cons
   a.src_istride = ps.src_istride;
   a.src_ostride = ps.src_ostride;
   a.tiles_per_outer = (ps.kind == KIND_COL) ? (u32)(ps.istride >> ps.f0) : 0;
+  a.grid = (u32)ps.grid;
   a.twist_lo = twist_lo;
   a.twist_hi = twist_hi;
   a.twist_shift = ps.twist_shift;

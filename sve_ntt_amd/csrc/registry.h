@@ -52,6 +52,14 @@ template <int LOGL, int MODE>
 using ColTileNarrow = TileNTT<LOGL + NARROW_F0, NARROW_F0, LOGL, REG_LOGE, MODE, true,
                               typename DefaultSteps<LOGL>::type>;
 
+// Slim COL tiles (T = 4, 32-byte segments; the XCD-aware tile order of
+// TileNTT::locate lets one L2 merge the two halves of a 64-byte line): half the
+// LDS of the T = 8 tile, so two workgroups share a CU.
+constexpr int SLIM_F0 = 2;
+template <int LOGL, int MODE>
+using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
+                            typename DefaultSteps<LOGL>::type>;
+
 template <class Status, class Stream> struct KernelEntryT {
   int kind, logl, dir, flag;
   int logt, f0, threads;
@@ -99,6 +107,12 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
       SVENTT_COL_ENTRIES(4),  SVENTT_COL_ENTRIES(5),  SVENTT_COL_ENTRIES(6),
       SVENTT_COL_ENTRIES(7),  SVENTT_COL_ENTRIES(8),  SVENTT_COL_ENTRIES(9),
       SVENTT_COL_ENTRIES(10), SVENTT_COL_ENTRIES(11),
+      make_entry<ColTileSlim<10, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),
+      make_entry<ColTileSlim<10, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
+      make_entry<ColTileSlim<11, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),
+      make_entry<ColTileSlim<11, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
+      make_entry<ColTileSlim<12, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),
+      make_entry<ColTileSlim<12, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
   };
   for (const Entry &e : table)
     if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0) return &e;
@@ -108,7 +122,9 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
 // Shape facts the host planner needs without instantiating anything.
 // log2 of the tile width for a column pass of length 2^logl over 2^logs columns
 // (-1: fewer columns than the narrowest tile).
-inline int registry_col_f0(int logl, int logs) {
+inline int registry_col_f0(int logl, int logs, bool slim = false) {
+  if (slim && logl >= 10 && logl <= 12 && logs >= SLIM_F0) return SLIM_F0;
+  if (logl > 11) return -1;
   if (logs >= col_f0(logl)) return col_f0(logl);
   if (logs >= NARROW_F0 && logl <= 8) return NARROW_F0;
   return -1;

@@ -54,6 +54,7 @@ struct PassArgs {
   u64 src_istride;
   u64 src_ostride;
   u32 tiles_per_outer;  // columns / T
+  u32 grid;             // workgroups in this launch
   // twist of the pass (six-step twiddle, layer/sve/generic.hpp:95-105,169-188):
   // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
   const u64 *twist_lo;
@@ -116,6 +117,11 @@ struct TileNTT {
   F64_HD static Tile locate(const PassArgs &a, u32 block) {
     Tile t;
     if constexpr (COL) {
+      // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so
+      // blocks b and b+8 share an L2.  Give each XCD a contiguous run of tiles: adjacent
+      // column tiles (which share 128-byte lines when T*8 < 128) then meet in one L2
+      // instead of being fetched by two.  Placement affects speed only.
+      if ((a.grid & 7u) == 0) block = (block & 7u) * (a.grid >> 3) + (block >> 3);
       const u32 o = block / a.tiles_per_outer, ct = block - o * a.tiles_per_outer;
       t.c0 = ct * (u32)T;
       t.base = (u64)o * a.ostride + t.c0;
