@@ -81,12 +81,22 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    # One rank per GPU.  SVENTT_BENCH_REHEARSE=1 lets more ranks than GPUs share a card
+    # over gloo (RCCL refuses that) to rehearse this script on a one-GPU box; such a
+    # run is marked in `config` and is not a scaling measurement.
+    rehearsal = world > ndev and os.environ.get("SVENTT_BENCH_REHEARSE") == "1"
+    if world > ndev and not rehearsal:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPUs (one rank per GPU)")
+    torch.cuda.set_device(local_rank % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -138,7 +148,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -146,10 +156,21 @@ def main() -> None:
     phase_ms = [float(np.mean([events[k][i].elapsed_time(events[k][i + 1])
                                for k in range(args.steps)])) for i in range(npass)]
     names = desc.split(" | ")
-    dom = int(np.argmax(phase_ms))
+    if len(names) != npass:
+        names = [f"phase {i}" for i in range(npass)]
+    kernels = [i for i in range(npass) if names[i] != "all-to-all"]
+    dom = max(kernels, key=lambda i: phase_ms[i])  # dominant KERNEL (the exchange is not one)
     dom_bytes = ALGO_BYTES_PER_ELEMENT * n_local  # each pass reads+writes every local element once
     achieved = dom_bytes / (phase_ms[dom] * 1e-3)
     device_ms = float(sum(phase_ms))
+    # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+    # (tools/pmc_run.sh; FETCH_SIZE corrected per MI355X_MICROARCH.md), keyed by kernel name
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f).get("bytes_per_launch", {}).get(names[dom])
+    except (OSError, ValueError):
+        pass
 
     out = {
         "metric": "forward-NTT uint64 elements/s at N=2^24; achieved HBM GB/s vs peak",
@@ -167,20 +188,20 @@ def main() -> None:
         "config": {
             "workload": f"forward NTT, N=2^{LOG2N}{'' if world == 1 else ' per GPU, one sharded transform of 2^%d' % (LOG2N + int(np.log2(world)))}, "
                         "p=0xfffffc6e80000001, g=3, out-of-place, bit-reversed output",
-            "plan": parallelism,
+            "plan": parallelism + (" [REHEARSAL: ranks share one GPU, gloo]" if rehearsal else ""),
             "elements_per_step": n_total,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": names[dom] if dom < len(names) else f"phase {dom}",
+            "kernel": names[dom],
             "achieved": achieved / 1e9,
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": dom_bytes,
             "kernel_ms": phase_ms[dom],
-            "all_phases_ms": dict(zip(names, phase_ms)) if len(names) == npass else phase_ms,
+            "all_phases_ms": [[names[i], phase_ms[i]] for i in range(npass)],
             "transform_device_ms": device_ms,
             "transform_frac": (ALGO_BYTES_PER_ELEMENT * n_local / (device_ms * 1e-3)) / HBM_PEAK,
         },

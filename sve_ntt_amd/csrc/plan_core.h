@@ -61,9 +61,14 @@ enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u };
 
 // Tuning knobs (environment, read once).  SVENTT_COL_SLIM=0/1: 4-column instead of
 // 8-column tiles for column passes of length >= 2^10 (two workgroups per CU).
+// SVENTT_TWIST_FULL_LOG2=k: column passes whose block has at most 2^k elements keep
+// their six-step twiddles as one full table in HBM (8 bytes per block element, read
+// once per transform with the block's own addressing) instead of composing them from
+// two small tables per element; 0 disables.
 struct Tuning {
   bool col_slim;
   int max_col_logl;
+  int twist_full_log2;
 };
 inline const Tuning &tuning(void) {
   static const Tuning t = [] {
@@ -71,6 +76,8 @@ inline const Tuning &tuning(void) {
     const char *e = std::getenv("SVENTT_COL_SLIM");
     x.col_slim = e ? (std::atoi(e) != 0) : false;
     x.max_col_logl = x.col_slim ? 12 : MAX_COL_LOGL;
+    e = std::getenv("SVENTT_TWIST_FULL_LOG2");
+    x.twist_full_log2 = e ? std::atoi(e) : 0;  // measured slower on MI355X (r01): off
     return x;
   }();
   return t;
@@ -432,8 +439,11 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
 
 // Kernel arguments of a pass, given where its tables live.
 inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, const u64 *src,
-                          const u64 *stage, const u64 *twist_lo, const u64 *twist_hi) {
+                          const u64 *stage, const u64 *twist_lo, const u64 *twist_hi,
+                          const u64 *twist_full = nullptr) {
   PassArgs a{};
+  a.twist_full = twist_full;
+  a.twist_full_ld = ps.istride;
   a.dst = dst;
   a.src = src;
   a.f = pl.f;

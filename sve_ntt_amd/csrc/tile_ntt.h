@@ -59,6 +59,11 @@ struct PassArgs {
   // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
   const u64 *twist_lo;
   const u64 *twist_hi;
+  // optional: the same factors materialised for one block, laid out like the block
+  // itself (entry i*twist_full_ld + c) so that the twist is one coalesced load instead
+  // of two gathers and a product; null = use the two-level tables
+  const u64 *twist_full;
+  u64 twist_full_ld;
   u32 twist_shift;
   u64 twist_col_offset; // added to the column index (rank offset of a sharded column pass)
   u64 scale;            // ROW inverse with FLAG: L^{-1} (Montgomery form)
@@ -160,6 +165,8 @@ struct TileNTT {
   // six-step twiddle of element I: omega_M^(bitrev_L(i) * c)
   F64_HD static u64 twist(const PassArgs &a, const Tile &t, u32 I) {
     const u32 i = I >> F0;
+    if (a.twist_full != nullptr)  // uniform branch
+      return a.twist_full[(u64)i * a.twist_full_ld + t.c0 + (I & (u32)(T - 1))];
     const u32 br = LOGL ? (bitrev32(i) >> (32 - LOGL)) : 0u;
     const u64 e = (u64)br * (a.twist_col_offset + t.c0 + (I & (u32)(T - 1)));
     const u64 lo = a.twist_lo[e & ((1ull << a.twist_shift) - 1)];
