@@ -14,7 +14,4 @@ const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0);
 hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, const Field &f,
                             u64 r2, hipStream_t stream);
 
-hipError_t launch_fill_twist(u64 *out, u32 logl, u32 logs, u64 col_offset, const u64 *lo,
-                             const u64 *hi, u32 shift, const Field &f, hipStream_t stream);
-
 }  // namespace sventt_hip

@@ -59,30 +59,6 @@ hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, con
   return hipGetLastError();
 }
 
-// Materialises the six-step twiddles of one L x S block (plan construction only):
-// out[j*S + c] = omega_M^(bitrev_L(j) * (c + col_offset)), Montgomery form.
-__global__ __launch_bounds__(256) void fill_twist_kernel(u64 *out, u64 count, u32 logl, u32 logs,
-                                                         u64 col_offset, const u64 *lo,
-                                                         const u64 *hi, u32 shift, Field f) {
-  for (u64 k = blockIdx.x * 256ull + threadIdx.x; k < count; k += (u64)gridDim.x * 256ull) {
-    const u32 j = (u32)(k >> logs);
-    const u64 c = (k & ((1ull << logs) - 1)) + col_offset;
-    const u32 br = logl ? (__brev(j) >> (32 - logl)) : 0u;
-    const u64 e = (u64)br * c;
-    out[k] = montmul(hi[e >> shift], lo[e & ((1ull << shift) - 1)], f);
-  }
-}
-
-hipError_t launch_fill_twist(u64 *out, u32 logl, u32 logs, u64 col_offset, const u64 *lo,
-                             const u64 *hi, u32 shift, const Field &f, hipStream_t stream) {
-  const u64 count = 1ull << (logl + logs);
-  u64 blocks = (count + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(fill_twist_kernel, dim3((u32)blocks), dim3(256), 0, stream, out, count, logl,
-                     logs, col_offset, lo, hi, shift, f);
-  return hipGetLastError();
-}
-
 // ---- registry -------------------------------------------------------------------
 template <class TN> struct HipLauncher {
   static hipError_t launch(const PassArgs &a, u32 grid, hipStream_t stream) {

@@ -33,7 +33,7 @@ int fail(int code, const std::string &msg) {
 
 struct DevicePass {
   const KernelEntry *kernel = nullptr;
-  u64 *stage = nullptr, *twist_lo = nullptr, *twist_hi = nullptr, *twist_full = nullptr;
+  u64 *stage = nullptr, *twist_lo = nullptr, *twist_hi = nullptr;
 };
 
 int upload(const std::vector<u64> &host, u64 *&dev) {
@@ -65,7 +65,7 @@ int check_device() {
   return SVENTT_OK;
 }
 
-int realize(const HostPlan &pl, const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
+int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
   dev.resize(host.size());
   for (size_t i = 0; i < host.size(); ++i) {
     const HostPass &h = host[i];
@@ -78,15 +78,6 @@ int realize(const HostPlan &pl, const std::vector<HostPass> &host, std::vector<D
     if ((rc = upload(h.stage, d.stage))) return rc;
     if ((rc = upload(h.twist_lo, d.twist_lo))) return rc;
     if ((rc = upload(h.twist_hi, d.twist_hi))) return rc;
-    // Column passes with a moderate block keep the whole twist of one block in HBM.
-    const int logs = ilog2_u64(h.istride);
-    if (h.kind == KIND_COL && h.logl + logs <= tuning().twist_full_log2 &&
-        h.src_istride == h.dst_istride) {
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.twist_full), sizeof(u64) << (h.logl + logs)));
-      HIP_TRY(launch_fill_twist(d.twist_full, (u32)h.logl, (u32)logs, h.twist_col_offset, d.twist_lo,
-                                d.twist_hi, h.twist_shift, pl.f, nullptr));
-      HIP_TRY(hipStreamSynchronize(nullptr));
-    }
   }
   return SVENTT_OK;
 }
@@ -96,7 +87,7 @@ int finish_plan(sventt_plan *pl, int rc, const std::string &err, sventt_plan **o
     delete pl;
     return fail(rc == PLAN_ERR_INVALID_ARGUMENT ? SVENTT_ERR_INVALID_ARGUMENT : SVENTT_ERR_LOGIC, err);
   }
-  if ((rc = realize(pl->host, pl->host.fwd, pl->fwd)) || (rc = realize(pl->host, pl->host.inv, pl->inv))) {
+  if ((rc = realize(pl->host.fwd, pl->fwd)) || (rc = realize(pl->host.inv, pl->inv))) {
     sventt_plan_destroy(pl);
     return rc;
   }
@@ -112,7 +103,7 @@ int run_pass(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const 
              hipStream_t stream) {
   const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[index];
   const DevicePass &d = (inverse ? pl->inv : pl->fwd)[index];
-  const PassArgs a = make_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi, d.twist_full);
+  const PassArgs a = make_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi);
   HIP_TRY(d.kernel->launch(a, (u32)h.grid, stream));
   return SVENTT_OK;
 }
@@ -215,7 +206,6 @@ void sventt_plan_destroy(sventt_plan *pl) {
       if (d.stage) (void)hipFree(d.stage);
       if (d.twist_lo) (void)hipFree(d.twist_lo);
       if (d.twist_hi) (void)hipFree(d.twist_hi);
-      if (d.twist_full) (void)hipFree(d.twist_full);
     }
   if (pl->staging) (void)hipFree(pl->staging);
   delete pl;

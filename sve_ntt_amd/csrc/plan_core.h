@@ -61,23 +61,20 @@ enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u };
 
 // Tuning knobs (environment, read once).  SVENTT_COL_SLIM=0/1: 4-column instead of
 // 8-column tiles for column passes of length >= 2^10 (two workgroups per CU).
-// SVENTT_TWIST_FULL_LOG2=k: column passes whose block has at most 2^k elements keep
-// their six-step twiddles as one full table in HBM (8 bytes per block element, read
-// once per transform with the block's own addressing) instead of composing them from
-// two small tables per element; 0 disables.
+// (Tried and dropped in r01: keeping the six-step twiddles of a whole block as one
+// table in HBM instead of composing them from two small tables per element.  It
+// saves ~40 VALU instructions per element but the extra 8 B/element of HBM reads
+// made the column pass 8-12 % slower.)
 struct Tuning {
   bool col_slim;
   int max_col_logl;
-  int twist_full_log2;
 };
 inline const Tuning &tuning(void) {
   static const Tuning t = [] {
     Tuning x;
     const char *e = std::getenv("SVENTT_COL_SLIM");
-    x.col_slim = e ? (std::atoi(e) != 0) : false;
+    x.col_slim = e ? (std::atoi(e) != 0) : true;  // r01: 2^24 forward column pass 150 -> 138 us
     x.max_col_logl = x.col_slim ? 12 : MAX_COL_LOGL;
-    e = std::getenv("SVENTT_TWIST_FULL_LOG2");
-    x.twist_full_log2 = e ? std::atoi(e) : 0;  // measured slower on MI355X (r01): off
     return x;
   }();
   return t;
@@ -154,6 +151,10 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
     if (logl > tuning().max_col_logl) {
       err = "column pass longer than one workgroup can hold";
       return PLAN_ERR_LOGIC;
+    }
+    if (twist_order_log2 > 32) {
+      err = "transforms longer than 2^32 points are not supported";  // 32-bit twist exponents
+      return PLAN_ERR_INVALID_ARGUMENT;
     }
     build_twist_tables(f, pl.g, twist_order_log2, inverse, inverse ? scale_plain : 1, ps.twist_lo,
                        ps.twist_hi, ps.twist_shift);
@@ -439,11 +440,8 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
 
 // Kernel arguments of a pass, given where its tables live.
 inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, const u64 *src,
-                          const u64 *stage, const u64 *twist_lo, const u64 *twist_hi,
-                          const u64 *twist_full = nullptr) {
+                          const u64 *stage, const u64 *twist_lo, const u64 *twist_hi) {
   PassArgs a{};
-  a.twist_full = twist_full;
-  a.twist_full_ld = ps.istride;
   a.dst = dst;
   a.src = src;
   a.f = pl.f;

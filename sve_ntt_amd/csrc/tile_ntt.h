@@ -59,11 +59,6 @@ struct PassArgs {
   // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
   const u64 *twist_lo;
   const u64 *twist_hi;
-  // optional: the same factors materialised for one block, laid out like the block
-  // itself (entry i*twist_full_ld + c) so that the twist is one coalesced load instead
-  // of two gathers and a product; null = use the two-level tables
-  const u64 *twist_full;
-  u64 twist_full_ld;
   u32 twist_shift;
   u64 twist_col_offset; // added to the column index (rank offset of a sharded column pass)
   u64 scale;            // ROW inverse with FLAG: L^{-1} (Montgomery form)
@@ -156,20 +151,33 @@ struct TileNTT {
   }
 
   F64_HD static bool in_range(const PassArgs &a, const Tile &t, u32 I) {
-    if constexpr (COL)
+    // Only a ROW tile holding several rows can straddle the end of a ragged batch; a
+    // tile that is one whole row (or whole columns) is either live or not launched.
+    if constexpr (COL || LOGT == LOGL)
       return true;
     else
       return t.base + I < a.total;
   }
 
-  // six-step twiddle of element I: omega_M^(bitrev_L(i) * c)
-  F64_HD static u64 twist(const PassArgs &a, const Tile &t, u32 I) {
-    const u32 i = I >> F0;
-    if (a.twist_full != nullptr)  // uniform branch
-      return a.twist_full[(u64)i * a.twist_full_ld + t.c0 + (I & (u32)(T - 1))];
-    const u32 br = LOGL ? (bitrev32(i) >> (32 - LOGL)) : 0u;
-    const u64 e = (u64)br * (a.twist_col_offset + t.c0 + (I & (u32)(T - 1)));
-    const u64 lo = a.twist_lo[e & ((1ull << a.twist_shift) - 1)];
+  // Six-step twiddle of element I = I0 | v<<lo: omega_M^(bitrev_L(i) * c).  bitrev is
+  // linear over disjoint bit fields, so the exponent splits into a per-set part
+  // (twist_e0) and c times a compile-time constant per element (twist_bv).
+  // e < M <= 2^32 (the planner never builds a larger block): 32-bit arithmetic.
+  F64_HD static u32 twist_col(const PassArgs &a, const Tile &t, u32 I0) {
+    return (u32)a.twist_col_offset + t.c0 + (I0 & (u32)(T - 1));
+  }
+  F64_HD static u32 twist_e0(u32 col, u32 I0) {
+    const u32 i0 = I0 >> F0;
+    return col * (LOGL ? (bitrev32(i0) >> (32 - LOGL)) : 0u);
+  }
+  static constexpr u32 twist_bv(int v, int LO) {
+    // bitrev_LOGL(v << LO), by hand so that it folds at compile time
+    u32 x = (u32)v << LO, r = 0;
+    for (int b = 0; b < LOGL; ++b) r |= ((x >> b) & 1u) << (LOGL - 1 - b);
+    return r;
+  }
+  F64_HD static u64 twist_lookup(const PassArgs &a, u32 e) {
+    const u64 lo = a.twist_lo[e & ((1u << a.twist_shift) - 1u)];
     const u64 hi = a.twist_hi[e >> a.twist_shift];
     return montmul(hi, lo, a.f);
   }
@@ -193,18 +201,36 @@ struct TileNTT {
       const u32 s = tid + (u32)g * NT;
       const u32 s_low = s & ((1u << lo) - 1u);
       const u32 I0 = ((s >> lo) << hi) | s_low;
+      // lds_phys is XOR-linear and I0 has zeros where v goes, so
+      // phys(I0 | v<<lo) = phys(I0) ^ phys(v<<lo): one v_xor with a literal per element
+      const u32 P0 = lds_phys(I0);
+      // HBM side: the set's elements sit a uniform stride apart (rows of the block for a
+      // COL tile), so one 64-bit address per set and constant multiples of the stride.
+      constexpr bool twisted = COL && FLAG;
+      u32 tw_col = 0, tw_e0 = 0;
+      if constexpr (twisted && (from_hbm || to_hbm)) {
+        tw_col = twist_col(a, t, I0);
+        tw_e0 = twist_e0(tw_col, I0);
+      }
       // ---- gather ----------------------------------------------------------
+      if constexpr (from_hbm) {
+        const u64 vstride = COL ? (a.src_istride << LO) : (1ull << lo);
+        const u64 *p0 = a.src + saddr(a, t, I0);
+        u64 tw[R];
+        if constexpr (twisted && MODE == MODE_INV) {
 #pragma unroll
-      for (int v = 0; v < R; ++v) {
-        const u32 I = I0 | ((u32)v << lo);
-        u64 val;
-        if constexpr (from_hbm) {
-          val = in_range(a, t, I) ? a.src[saddr(a, t, I)] : 0;
-          if constexpr (COL && FLAG && MODE == MODE_INV) val = montmul(val, twist(a, t, I), a.f);
-        } else {
-          val = lds[lds_phys(I)];
+          for (int v = 0; v < R; ++v) tw[v] = twist_lookup(a, tw_e0 + tw_col * twist_bv(v, LO));
         }
-        x[g * R + v] = val;
+#pragma unroll
+        for (int v = 0; v < R; ++v)
+          x[g * R + v] = in_range(a, t, I0 | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
+        if constexpr (twisted && MODE == MODE_INV) {
+#pragma unroll
+          for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], tw[v], a.f);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
       }
       // ---- k fused stages ----------------------------------------------------
 #pragma unroll
@@ -239,16 +265,22 @@ struct TileNTT {
         }
       }
       // ---- scatter -----------------------------------------------------------
+      if constexpr (to_hbm) {
+        const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
+        u64 *p0 = a.dst + gaddr(a, t, I0);
+        if constexpr (twisted && MODE == MODE_FWD) {
+          u64 tw[R];
 #pragma unroll
-      for (int v = 0; v < R; ++v) {
-        const u32 I = I0 | ((u32)v << lo);
-        u64 val = x[g * R + v];
-        if constexpr (to_hbm) {
-          if constexpr (COL && FLAG && MODE == MODE_FWD) val = montmul(val, twist(a, t, I), a.f);
-          if (in_range(a, t, I)) a.dst[gaddr(a, t, I)] = val;
-        } else {
-          lds[lds_phys(I)] = val;
+          for (int v = 0; v < R; ++v) tw[v] = twist_lookup(a, tw_e0 + tw_col * twist_bv(v, LO));
+#pragma unroll
+          for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], tw[v], a.f);
         }
+#pragma unroll
+        for (int v = 0; v < R; ++v)
+          if (in_range(a, t, I0 | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
+      } else {
+#pragma unroll
+        for (int v = 0; v < R; ++v) lds[P0 ^ lds_phys((u32)v << lo)] = x[g * R + v];
       }
     }
   }

@@ -89,8 +89,9 @@ def test_plan_shapes():
     assert [(x["kind"], x["logl"]) for x in s] == [(1, 8), (0, 9)]
     # BASELINE config #3: 2^24 = 2^11 columns x 2^13 rows, 8-column tiles
     s = simlib.plan_shape(P, G, 1 << 24)
-    assert [(x["kind"], x["logl"], x["f0"]) for x in s] == [(1, 11, 3), (0, 13, 0)]
-    assert s[0]["grid"] == (1 << 13) // 8 and s[1]["grid"] == 1 << 11
+    assert [(x["kind"], x["logl"]) for x in s] == [(1, 11), (0, 13)]
+    assert s[0]["f0"] in (2, 3)  # 4-column tiles by default, 8 with SVENTT_COL_SLIM=0
+    assert s[0]["grid"] == (1 << 13) >> s[0]["f0"] and s[1]["grid"] == 1 << 11
     # config #4: one workgroup per N = 2^12 transform
     s = simlib.plan_shape(P, G, 1 << 12, batch=1 << 16)
     assert [(x["kind"], x["logl"], x["grid"]) for x in s] == [(0, 12, 1 << 16)]
