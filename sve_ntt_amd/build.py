@@ -17,7 +17,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsventt_hip.so")
 SOURCES = ["kernels.hip", "plan.hip"]
-HEADERS = ["field64.h", "tile_ntt.h", "kernels.h", os.path.join(ROOT, "include", "sventt_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
+    os.path.join(ROOT, "include", "sventt_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
          "-Wno-unused-parameter", "-fno-gpu-rdc"]

@@ -110,7 +110,7 @@ def test_planner_errors():
     with pytest.raises(simlib.SimError, match="n0_log2"):
         simlib.plan_shape(P, G, 1 << 10, n0_log2=10)
     with pytest.raises(simlib.SimError, match="n0_log2"):
-        simlib.plan_shape(P, G, 1 << 20, n0_log2=12)
+        simlib.plan_shape(P, G, 1 << 20, n0_log2=13)
     with pytest.raises(simlib.SimError, match="too few columns"):
         simlib.plan_shape(P, G, 1 << 6, n0_log2=5)  # 2 columns: narrower than the narrowest tile
     with pytest.raises(simlib.SimError, match="generate"):
