@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsventt_hip.so")
+# SVENTT_HIP_LIBRARY: load another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("SVENTT_HIP_LIBRARY") or os.path.join(_HERE, "libsventt_hip.so")
 
 SVENTT_OK = 0
 SVENTT_ERR_INVALID_ARGUMENT = -1
