@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Times the LOCAL phases one rank runs in the sharded six-step (no communication),
+for world sizes 2, 4, 8 at 2^24 elements per rank -- what bench.py --gpus G does
+between the all-to-all.  Run on a one-GPU box: python tools/bench_sharded_local.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sve_ntt_amd as eng  # noqa: E402
+from sve_ntt_amd.sharded import HipShardEngine  # noqa: E402
+
+n_local = 1 << 24
+rng = np.random.default_rng(0)
+src = torch.from_numpy(rng.integers(0, eng.BASELINE_MODULUS.modulus, size=n_local, dtype=np.uint64)
+                       .view(np.int64)).cuda()
+work = torch.empty_like(src)
+recv = torch.empty_like(src)
+out = torch.empty_like(src)
+iters = 30
+for world in (2, 4, 8):
+    e = HipShardEngine(eng.BASELINE_MODULUS, n_local * world, 11, 0, world)
+    names = e.describe().split(" | ")
+
+    def run(ev=None):
+        k = 0
+        if ev: ev[k].record()
+        e.columns(False, work, src); k += 1
+        if ev: ev[k].record()
+        for i in range(e.rows_passes):
+            e.rows_pass(False, i, out, work if i == 0 else out); k += 1
+            if ev: ev[k].record()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    nph = 1 + e.rows_passes
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(nph + 1)] for _ in range(iters)]
+    for it in range(iters):
+        run(evs[it])
+    torch.cuda.synchronize()
+    ms = [float(np.median([evs[it][i].elapsed_time(evs[it][i + 1]) for it in range(iters)])) for i in range(nph)]
+    local = [nm for nm in names if nm != "all-to-all"]
+    print(f"world={world}: " + ", ".join(f"{nm}: {t * 1e3:.0f} us" for nm, t in zip(local, ms)) +
+          f"  | local total {sum(ms) * 1e3:.0f} us per 2^24 elements")
