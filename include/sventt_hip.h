@@ -132,6 +132,25 @@ int sventt_sharded_rows_plan_create(uint64_t p, uint64_t g, uint64_t n,
 int sventt_sharded_columns(const sventt_plan *plan, int inverse,
                            uint64_t *dst, const uint64_t *src, void *stream);
 
+/*
+ * Pipelining the exchange.  A column pass (pass_index must name one) can be run on
+ * chunk `chunk` of `nchunks` equal column ranges at a time, so that the all-to-all
+ * of one chunk overlaps the passes of its neighbours.  A side marked compact is a
+ * buffer holding only that chunk's columns (leading dimensions divided by nchunks,
+ * column index restarting at 0):
+ *   forward: column plan pass 0, dst compact  -> work_k = R x (Cl/nchunks), whose row
+ *            blocks are the all-to-all chunks; rows plan pass 0, src compact, reads the
+ *            received recv_k[s][q][Cl/nchunks] and writes whole rows;
+ *   inverse: rows plan last pass with dst compact, column plan pass 0 with src compact.
+ */
+/* Column tiles per block of a column pass (0 for a row pass): nchunks must divide it. */
+uint64_t sventt_plan_pass_tiles_per_block(const sventt_plan *plan, int inverse,
+                                          int pass_index);
+int sventt_run_pass_chunk(const sventt_plan *plan, int inverse, int pass_index,
+                          uint64_t *dst, const uint64_t *src, uint32_t chunk,
+                          uint32_t nchunks, int dst_compact, int src_compact,
+                          void *stream);
+
 /* Introspection (get_m(): wrapper.hpp:48; modulus_type: wrapper.hpp:32). */
 uint64_t sventt_plan_n(const sventt_plan *plan);
 uint64_t sventt_plan_batch(const sventt_plan *plan);

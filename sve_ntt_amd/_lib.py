@@ -35,6 +35,8 @@ SYMBOLS = {
     "sventt_inverse": (_int, [_vp, _vp, _vp, _vp]),
     "sventt_plan_num_passes": (_int, [_vp, _int]),
     "sventt_run_pass": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
+    "sventt_plan_pass_tiles_per_block": (_u64, [_vp, _int, _int]),
+    "sventt_run_pass_chunk": (_int, [_vp, _int, _int, _vp, _vp, _u32, _u32, _int, _int, _vp]),
     "sventt_sharded_plan_create": (_int, [_u64, _u64, _u64, _u32, _int, _int, _u32,
                                           ctypes.POINTER(_vp)]),
     "sventt_sharded_rows_plan_create": (_int, [_u64, _u64, _u64, _u32, _int, _int, _u32,

@@ -233,6 +233,33 @@ int sventt_run_pass(const sventt_plan *pl, int inverse, int pass_index, uint64_t
   return run_pass(pl, inverse != 0, (size_t)pass_index, dst, src, static_cast<hipStream_t>(stream));
 }
 
+uint64_t sventt_plan_pass_tiles_per_block(const sventt_plan *pl, int inverse, int pass_index) {
+  if (!pl) return 0;
+  const std::vector<HostPass> &passes = inverse ? pl->host.inv : pl->host.fwd;
+  if (pass_index < 0 || (size_t)pass_index >= passes.size()) return 0;
+  const HostPass &h = passes[(size_t)pass_index];
+  return h.kind == KIND_COL ? (h.istride >> h.f0) : 0;
+}
+
+int sventt_run_pass_chunk(const sventt_plan *pl, int inverse, int pass_index, uint64_t *dst,
+                          const uint64_t *src, uint32_t chunk, uint32_t nchunks, int dst_compact,
+                          int src_compact, void *stream) {
+  if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t npass = (inverse ? pl->inv : pl->fwd).size();
+  if (pass_index < 0 || (size_t)pass_index >= npass)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "pass index out of range");
+  const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[(size_t)pass_index];
+  const DevicePass &d = (inverse ? pl->inv : pl->fwd)[(size_t)pass_index];
+  PassArgs a;
+  u32 grid = 0;
+  std::string err;
+  if (make_chunk_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi, chunk, nchunks,
+                      dst_compact != 0, src_compact != 0, a, grid, err))
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, err);
+  HIP_TRY(d.kernel->launch(a, grid, static_cast<hipStream_t>(stream)));
+  return SVENTT_OK;
+}
+
 int sventt_sharded_rows_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank,
                                     int nranks, uint32_t flags, sventt_plan **out) {
   if (!out) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null plan pointer");

@@ -461,6 +461,41 @@ inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, cons
   return a;
 }
 
+// The same pass restricted to chunk `chunk` of `nchunks` equal column ranges of every
+// block.  A "compact" side is a buffer that holds only that chunk's columns: its
+// strides shrink by nchunks and its column index restarts at 0.  (The pipelined
+// all-to-all of the sharded transform: column pass chunk -> exchange chunk -> gather
+// chunk.)  Returns the launch size in `grid`.
+inline int make_chunk_args(const HostPlan &pl, const HostPass &ps, u64 *dst, const u64 *src,
+                           const u64 *stage, const u64 *twist_lo, const u64 *twist_hi, u32 chunk,
+                           u32 nchunks, bool dst_compact, bool src_compact, PassArgs &a, u32 &grid,
+                           std::string &err) {
+  a = make_args(pl, ps, dst, src, stage, twist_lo, twist_hi);
+  const u64 tiles_per_block = ps.istride >> ps.f0;
+  if (ps.kind != KIND_COL || nchunks == 0 || chunk >= nchunks || tiles_per_block % nchunks != 0) {
+    err = "pass cannot be split into that many column chunks";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const u64 tpc = tiles_per_block / nchunks;
+  const u64 launch = (pl.total / ps.block) * tpc;
+  const u32 first_col = (u32)((ps.istride / nchunks) * chunk);
+  a.tiles_per_outer = (u32)tpc;
+  a.ct_first = (u32)(tpc * chunk);
+  a.grid = (u32)launch;
+  if (dst_compact) {
+    a.istride /= nchunks;
+    a.ostride /= nchunks;
+    a.dst_col_bias = first_col;
+  }
+  if (src_compact) {
+    a.src_istride /= nchunks;
+    a.src_ostride /= nchunks;
+    a.src_col_bias = first_col;
+  }
+  grid = (u32)launch;
+  return PLAN_OK;
+}
+
 inline std::string describe_plan(const HostPlan &pl) {
   std::string d;
   char buf[96];

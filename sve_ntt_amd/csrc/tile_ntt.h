@@ -53,7 +53,13 @@ struct PassArgs {
   u64 ostride;
   u64 src_istride;
   u64 src_ostride;
-  u32 tiles_per_outer;  // columns / T
+  u32 tiles_per_outer;  // column tiles per block covered by THIS launch
+  // A launch may cover only a chunk of the columns (the sharded transform pipelines
+  // its all-to-all chunk by chunk): tile ct of the launch is column tile ct_first + ct,
+  // and a side whose buffer holds just the chunk rebases its column index by *_col_bias.
+  u32 ct_first;
+  u32 dst_col_bias;
+  u32 src_col_bias;
   u32 grid;             // workgroups in this launch
   // twist of the pass (six-step twiddle, layer/sve/generic.hpp:95-105,169-188):
   // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
@@ -123,9 +129,9 @@ struct TileNTT {
       // instead of being fetched by two.  Placement affects speed only.
       if ((a.grid & 7u) == 0) block = (block & 7u) * (a.grid >> 3) + (block >> 3);
       const u32 o = block / a.tiles_per_outer, ct = block - o * a.tiles_per_outer;
-      t.c0 = ct * (u32)T;
-      t.base = (u64)o * a.ostride + t.c0;
-      t.sbase = (u64)o * a.src_ostride + t.c0;
+      t.c0 = (a.ct_first + ct) * (u32)T;
+      t.base = (u64)o * a.ostride + (t.c0 - a.dst_col_bias);
+      t.sbase = (u64)o * a.src_ostride + (t.c0 - a.src_col_bias);
       t.live = true;
     } else {
       t.c0 = 0;

@@ -13,6 +13,9 @@ global transpose), and the row transforms split by row block:
          transform and reads the received pieces in place of a transposition
       out: rows [k*R/G, (k+1)*R/G) = slice k of the bit-reversed result
 
+Steps 1-3 are PIPELINED over ``chunks`` column ranges: the column pass writes
+chunk j compactly, its all-to-all is started asynchronously, the column pass of
+chunk j+1 runs meanwhile; the gather pass of chunk j waits only for exchange j.
 Every rank moves (G-1)/G of its data through the exchange once; nothing else
 crosses GPUs.  One process per GPU, ``torch.distributed`` (backend "nccl" is
 RCCL).  The local compute goes through the C ABI (include/sventt_hip.h); tests
@@ -21,6 +24,7 @@ inject a host stand-in to exercise this file's index logic with gloo.
 from __future__ import annotations
 
 import ctypes
+import os
 
 from . import _lib
 from . import Modulus, _buffer, _stream_handle
@@ -41,6 +45,10 @@ class HipShardEngine:
             ctypes.byref(self._rows)))
         self.n_local = n // nranks
         self.rows_passes = self._lib.sventt_plan_num_passes(self._rows, 0)
+        # the exchange can be cut into any number of chunks dividing both tile counts
+        self.chunk_limits = (
+            int(self._lib.sventt_plan_pass_tiles_per_block(self._cols, 0, 0)),
+            int(self._lib.sventt_plan_pass_tiles_per_block(self._rows, 0, 0)))
 
     def __del__(self):
         for name in ("_cols", "_rows"):
@@ -53,11 +61,21 @@ class HipShardEngine:
         return (self._lib.sventt_plan_describe(self._cols).decode() + " | all-to-all | " +
                 self._lib.sventt_plan_describe(self._rows).decode())
 
-    def columns(self, inverse: bool, dst, src, stream=None) -> None:
-        d, _k1 = _buffer(dst, self.n_local)
-        s, _k2 = _buffer(src, self.n_local)
-        _lib.check(self._lib.sventt_sharded_columns(self._cols, int(inverse), d, s,
-                                                    _stream_handle(stream)))
+    def _chunk(self, plan, inverse, index, dst, src, k, nchunks, dst_compact, src_compact):
+        d, _k1 = _buffer(dst, 1)
+        s, _k2 = _buffer(src, 1)
+        _lib.check(self._lib.sventt_run_pass_chunk(plan, int(inverse), index, d, s, k, nchunks,
+                                                   int(dst_compact), int(src_compact),
+                                                   _stream_handle(None)))
+
+    def columns_chunk(self, inverse: bool, dst, src, k: int, nchunks: int) -> None:
+        """forward: slab -> compact chunk k;  inverse: compact chunk k -> slab."""
+        self._chunk(self._cols, inverse, 0, dst, src, k, nchunks, not inverse, inverse)
+
+    def exchange_side_chunk(self, inverse: bool, dst, src, k: int, nchunks: int) -> None:
+        """forward: received chunk k -> whole rows (gather);  inverse: rows -> send chunk k."""
+        index = self.rows_passes - 1 if inverse else 0
+        self._chunk(self._rows, inverse, index, dst, src, k, nchunks, inverse, not inverse)
 
     def rows_pass(self, inverse: bool, index: int, dst, src, stream=None) -> None:
         d, _k1 = _buffer(dst, self.n_local)
@@ -71,11 +89,12 @@ class ShardedNTT:
 
     ``src``/``dst`` are this rank's ``n / world`` elements (int64 tensors holding
     uint64 residues): the column slab on the natural-order side, the row block on
-    the bit-reversed side.
+    the bit-reversed side.  ``chunks``: pieces the exchange is pipelined in
+    (default: env SVENTT_A2A_CHUNKS or 4, reduced to what the tile counts allow).
     """
 
     def __init__(self, modulus: Modulus, n: int, dist, r_log2: int = 11, engine=None,
-                 device=None):
+                 device=None, chunks: int | None = None):
         import torch
         self.dist = dist
         self.world = dist.get_world_size()
@@ -90,10 +109,23 @@ class ShardedNTT:
         self.engine = engine or HipShardEngine(modulus, n, r_log2, self.rank, self.world)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if engine is None else "cpu"
+        want = chunks if chunks is not None else int(os.environ.get("SVENTT_A2A_CHUNKS", "4"))
+        k = max(1, want)
+        while k > 1 and any(lim % k for lim in self.engine.chunk_limits):
+            k -= 1
+        self.chunks = k
         self._work = torch.empty(self.n_local, dtype=torch.int64, device=device)
         self._recv = torch.empty(self.n_local, dtype=torch.int64, device=device)
-        # phases: column pass, exchange, row passes
-        self.num_local_phases = 2 + self.engine.rows_passes
+        self._back = None  # third buffer, inverse only (allocated on first use)
+        # phases bench.py times with events: [column pass + exchanges started],
+        # [exchange waits + gather pass], then each remaining row pass
+        local = [nm for nm in self.engine.describe().split(" | ") if nm != "all-to-all"]
+        if len(local) == 1 + self.engine.rows_passes:
+            self.phase_names = ([local[0] + " (+ all-to-all started)",
+                                 "all-to-all wait + " + local[1]] + local[2:])
+        else:
+            self.phase_names = [f"phase {i}" for i in range(1 + self.engine.rows_passes)]
+        self.num_local_phases = 1 + self.engine.rows_passes
 
     def describe(self) -> str:
         return self.engine.describe()
@@ -102,46 +134,70 @@ class ShardedNTT:
         if events is not None:
             events[i].record()
 
+    def _piece(self, buf, k):
+        m = self.n_local // self.chunks
+        return buf[k * m:(k + 1) * m]
+
     def _exchange(self, out, inp):
-        """The one collective of the transform.  RCCL moves device buffers directly;
-        a gloo group (rehearsals on a box with fewer GPUs than ranks) cannot, so the
-        chunks are bounced through host memory there -- transport only, the
-        transforms on either side still run in the HIP kernels."""
+        """The one collective of the transform (per chunk).  Returns a waitable or None.
+        RCCL moves device buffers directly and asynchronously; a gloo group (rehearsals
+        on a box with fewer GPUs than ranks) cannot, so there the chunk is bounced
+        through host memory -- transport only, the transforms on either side still run
+        in the HIP kernels."""
         if inp.is_cuda and self.dist.get_backend() == "gloo":
             h_in, h_out = inp.cpu(), out.cpu()
             self.dist.all_to_all_single(h_out, h_in)
             out.copy_(h_out)
-        else:
-            self.dist.all_to_all_single(out, inp)
+            return None
+        if inp.is_cuda:
+            return self.dist.all_to_all_single(out, inp, async_op=True)
+        self.dist.all_to_all_single(out, inp)
+        return None
 
     def forward(self, dst, src, events=None):
         """natural-order column slab ``src`` -> bit-reversed row block ``dst``."""
-        e = self.engine
+        e, K = self.engine, self.chunks
+        pending = []
         self._mark(events, 0)
-        e.columns(False, self._work, src)
+        for k in range(K):
+            # chunk k of the column pass, written compactly: row block h of the piece
+            # is what rank h needs, so the piece is exchanged as is
+            e.columns_chunk(False, self._piece(self._work, k), src, k, K)
+            pending.append(self._exchange(self._piece(self._recv, k), self._piece(self._work, k)))
         self._mark(events, 1)
-        # chunk h of _work = rows [h*R/G, (h+1)*R/G) of the slab -> rank h
-        self._exchange(self._recv, self._work)
+        for k in range(K):
+            if pending[k] is not None:
+                pending[k].wait()
+            e.exchange_side_chunk(False, dst, self._piece(self._recv, k), k, K)
         self._mark(events, 2)
-        for i in range(e.rows_passes):
-            e.rows_pass(False, i, dst, self._recv if i == 0 else dst)
-            self._mark(events, 3 + i)
+        for i in range(1, e.rows_passes):
+            e.rows_pass(False, i, dst, dst)
+            self._mark(events, 2 + i)
         return dst
 
     def inverse(self, dst, src, events=None):
         """bit-reversed row block ``src`` -> natural-order column slab ``dst``."""
-        e = self.engine
-        k = e.rows_passes
+        import torch
+        e, K = self.engine, self.chunks
+        n_in_place = e.rows_passes - 1
+        rows, send = self._recv, self._work
+        if self._back is None:
+            self._back = torch.empty_like(send)
         cur = src
         self._mark(events, 0)
-        for i in range(k - 1):
-            e.rows_pass(True, i, self._work, cur)
-            cur = self._work
+        for i in range(n_in_place):
+            e.rows_pass(True, i, rows, cur)  # first one out of place, then in place on `rows`
+            cur = rows
             self._mark(events, 1 + i)
-        e.rows_pass(True, k - 1, self._recv, cur)  # scatters into piece layout
-        self._mark(events, k)
-        self._exchange(self._work, self._recv)
-        self._mark(events, k + 1)
-        e.columns(True, dst, self._work)
-        self._mark(events, k + 2)
+        pending = []
+        for k in range(K):
+            # the last rows pass scatters chunk k into piece layout; its exchange starts at once
+            e.exchange_side_chunk(True, self._piece(send, k), cur, k, K)
+            pending.append(self._exchange(self._piece(self._back, k), self._piece(send, k)))
+        self._mark(events, 1 + n_in_place)
+        for k in range(K):
+            if pending[k] is not None:
+                pending[k].wait()
+            e.columns_chunk(True, dst, self._piece(self._back, k), k, K)
+        self._mark(events, 2 + n_in_place)
         return dst

@@ -118,6 +118,41 @@ int sim_sharded_rows_pass(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, i
   return 0;
 }
 
+// Chunked column passes of the sharded transform (sventt_run_pass_chunk): which = 0 the
+// column plan's pass, which = 1 the rows plan's gather (forward pass 0) / scatter
+// (inverse last pass).
+int sim_sharded_chunk(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank, int nranks,
+                      int which, int inverse, uint32_t chunk, uint32_t nchunks, int dst_compact,
+                      int src_compact, uint64_t *dst, const uint64_t *src) {
+  HostPlan pl;
+  const u32 flags = inverse ? PLAN_INVERSE : PLAN_FORWARD;
+  int rc = which == 0 ? build_sharded_plan(pl, p, g, n, r_log2, rank, nranks, flags, g_err)
+                      : build_sharded_rows_plan(pl, p, g, n, r_log2, rank, nranks, flags, g_err);
+  if (rc) return rc;
+  const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
+  const HostPass &h = (which == 1 && inverse) ? passes.back() : passes.front();
+  const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
+      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
+  if (!e) return PLAN_ERR_LOGIC;
+  PassArgs a;
+  u32 grid = 0;
+  rc = make_chunk_args(pl, h, dst, src, h.stage.data(), h.twist_lo.data(), h.twist_hi.data(), chunk,
+                       nchunks, dst_compact != 0, src_compact != 0, a, grid, g_err);
+  if (rc) return rc;
+  e->launch(a, grid, 0);
+  return 0;
+}
+
+int64_t sim_sharded_tiles_per_block(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank,
+                                    int nranks, int which) {
+  HostPlan pl;
+  int rc = which == 0 ? build_sharded_plan(pl, p, g, n, r_log2, rank, nranks, PLAN_FORWARD, g_err)
+                      : build_sharded_rows_plan(pl, p, g, n, r_log2, rank, nranks, PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  const HostPass &h = pl.fwd.front();
+  return (int64_t)(h.istride >> h.f0);
+}
+
 // Planner introspection: writes up to `cap` entries of (kind, logl, f0, logt, grid) per pass.
 int sim_plan_shape(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch, int inverse,
                    int64_t *out, int cap) {

@@ -50,7 +50,9 @@ def main() -> None:
     if engine_kind == "sim":
         from tests.simlib import SimShardEngine
         engine = SimShardEngine(eng.BASELINE_MODULUS, n, r_log2, rank, world)
-    sh = ShardedNTT(eng.BASELINE_MODULUS, n, dist, r_log2=r_log2, engine=engine, device=device)
+    chunks = int(os.environ.get("CHUNKS", "4"))
+    sh = ShardedNTT(eng.BASELINE_MODULUS, n, dist, r_log2=r_log2, engine=engine, device=device,
+                    chunks=chunks)
 
     src = torch.from_numpy(slab.view(np.int64).copy()).to(device)
     dst = torch.full_like(src, 0x5555555555555555)
@@ -67,7 +69,7 @@ def main() -> None:
     flags = torch.tensor([int(ok_f), int(ok_i)], dtype=torch.int64, device=device)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(f"SHARDED world={world} n=2^{log2n} R=2^{r_log2} Rl={Rl} Cl={Cl} "
+        print(f"SHARDED world={world} n=2^{log2n} R=2^{r_log2} Rl={Rl} Cl={Cl} chunks={sh.chunks} "
               f"forward={'OK' if flags[0].item() else 'MISMATCH'} "
               f"inverse={'OK' if flags[1].item() else 'MISMATCH'}", flush=True)
     dist.destroy_process_group()

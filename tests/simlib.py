@@ -45,6 +45,11 @@ def load() -> ctypes.CDLL:
         L.sim_sharded_rows_num_passes.argtypes = [_u64, _u64, _u64, _u32, _int, _int]
         L.sim_sharded_rows_pass.restype = _int
         L.sim_sharded_rows_pass.argtypes = [_u64, _u64, _u64, _u32, _int, _int, _int, _int, _p64, _p64]
+        L.sim_sharded_chunk.restype = _int
+        L.sim_sharded_chunk.argtypes = [_u64, _u64, _u64, _u32, _int, _int, _int, _int, _u32, _u32,
+                                        _int, _int, _p64, _p64]
+        L.sim_sharded_tiles_per_block.restype = ctypes.c_int64
+        L.sim_sharded_tiles_per_block.argtypes = [_u64, _u64, _u64, _u32, _int, _int, _int]
         L.sim_plan_shape.restype = _int
         L.sim_plan_shape.argtypes = [_u64, _u64, _u64, _u32, _u64, _int,
                                      ctypes.POINTER(ctypes.c_int64), _int]
@@ -102,6 +107,8 @@ class SimShardEngine:
         self.rows_passes = self.L.sim_sharded_rows_num_passes(*self.args)
         if self.rows_passes < 0:
             raise SimError(self.L.sim_last_error().decode())
+        self.chunk_limits = (int(self.L.sim_sharded_tiles_per_block(*self.args, 0)),
+                             int(self.L.sim_sharded_tiles_per_block(*self.args, 1)))
 
     def describe(self) -> str:
         return "host replay"
@@ -110,10 +117,17 @@ class SimShardEngine:
     def _np(t):
         return t.numpy().view(np.uint64)
 
-    def columns(self, inverse, dst, src, stream=None):
-        rc = self.L.sim_sharded_columns(*self.args, int(inverse), _ptr(self._np(dst)), _ptr(self._np(src)))
+    def _chunk(self, which, inverse, dst, src, k, nchunks, dst_compact, src_compact):
+        rc = self.L.sim_sharded_chunk(*self.args, which, int(inverse), k, nchunks, int(dst_compact),
+                                      int(src_compact), _ptr(self._np(dst)), _ptr(self._np(src)))
         if rc:
             raise SimError(self.L.sim_last_error().decode())
+
+    def columns_chunk(self, inverse, dst, src, k, nchunks):
+        self._chunk(0, inverse, dst, src, k, nchunks, not inverse, inverse)
+
+    def exchange_side_chunk(self, inverse, dst, src, k, nchunks):
+        self._chunk(1, inverse, dst, src, k, nchunks, inverse, not inverse)
 
     def rows_pass(self, inverse, index, dst, src, stream=None):
         rc = self.L.sim_sharded_rows_pass(*self.args, int(inverse), index, _ptr(self._np(dst)),
