@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "sventt/modulus.hpp"
+#include "sventt/transposition.hpp"
 
 namespace sventt {
 
@@ -67,25 +68,6 @@ template <class modulus_type> class PAdic64SVE : public detail::modmul_tag<modul
 template <class modulus_type> class PAdic64Scalar : public detail::modmul_tag<modulus_type> {};
 template <class modulus_type> class FixedPoint64SVE : public detail::modmul_tag<modulus_type> {};
 template <class modulus_type> class FixedPoint64Scalar : public detail::modmul_tag<modulus_type> {};
-
-// ---- transposition tags --------------------------------------------------------
-// The reference tunes a dozen SVE transposes (transposition/sve/*.hpp); the GPU
-// passes address columns directly (the tile's addressing is the transpose), so
-// these only have to exist as types.
-template <std::uint64_t, std::uint64_t> class TransposeSVEInRegister {};
-template <std::uint64_t, std::uint64_t> class TransposeParallelSVEInRegister {};
-template <std::uint64_t, std::uint64_t> class TransposeSVEInRegisterRowFirst {};
-template <std::uint64_t, std::uint64_t> class TransposeParallelSVEInRegisterRowFirst {};
-template <std::uint64_t, std::uint64_t, std::uint64_t, std::uint64_t>
-class TransposeSVEInRegisterExplicitBlockingRowFirst {};
-template <std::uint64_t, std::uint64_t, std::uint64_t, std::uint64_t>
-class TransposeParallelSVEInRegisterExplicitBlockingRowFirst {};
-template <std::uint64_t, std::uint64_t, std::uint64_t, std::uint64_t>
-class TransposeParallelSVEInRegisterFullBlockingRowFirst {};
-template <std::uint64_t, std::uint64_t> class TransposeParallelSVEGatherRowFirst {};
-template <std::uint64_t, std::uint64_t> class TransposeParallelSVEGatherColumnFirst {};
-template <std::uint64_t, std::uint64_t> class TransposeParallelSVEGatherVectorIndexRowFirst {};
-template <std::uint64_t, std::uint64_t> class TransposeParallelSVEGatherVectorIndexColumnFirst {};
 
 // ---- butterfly layers -------------------------------------------------------------
 // <modmul, m, n, inverse_factor = 1, store_precomputation = true>: `radix` fused

@@ -19,30 +19,10 @@
 #include <stdexcept>
 #include <string>
 
+#include "sventt/status.hpp"
 #include "sventt_hip.h"
 
 namespace sventt {
-
-namespace detail {
-
-inline void throw_on_error(const int status) {
-  if (status == SVENTT_OK) {
-    return;
-  }
-  const std::string message{sventt_last_error()};
-  switch (status) {
-  case SVENTT_ERR_INVALID_ARGUMENT:
-    throw std::invalid_argument{message};
-  case SVENTT_ERR_ALLOC:
-    throw std::bad_alloc{};
-  case SVENTT_ERR_LOGIC:
-    throw std::logic_error{message};
-  default:
-    throw std::runtime_error{"sventt-hip: " + message};
-  }
-}
-
-} // namespace detail
 
 template <class kernel_type_> class NTT {
 public:

@@ -158,13 +158,30 @@ uint64_t sventt_plan_modulus(const sventt_plan *plan);
 /* Human-readable description of the passes ("col 2^11 x T8 | row 2^13"). */
 const char *sventt_plan_describe(const sventt_plan *plan);
 
-/* Element-wise helpers on device or host arrays of `count` residues:
+/* Element-wise product of device arrays of `count` residues in [0, p):
  * dst[i] = a[i]*b[i] mod p.  The caller of the reference does this between a
  * forward and an inverse transform
  * (examples/magic-series/gaussian-polynomial.hpp:201-212). */
 int sventt_pointwise_multiply(const sventt_plan *plan, uint64_t *dst,
                               const uint64_t *a, const uint64_t *b,
                               uint64_t count, void *stream);
+
+/* Stand-alone transposition of a matrix of 64-bit words,
+ *   dst[ld_dst*c + r] = src[ld_src*r + c],  r < src_rows, c < src_cols,
+ * replacing TransposeParallelSVEInRegister<br,bc>::transpose(dst, src, src_rows,
+ * src_cols, ld_dst, ld_src) (transposition/sve/in-register.hpp:115-206) and its
+ * relatives; leading dimensions may carry padding (ld_src >= src_cols,
+ * ld_dst >= src_rows), any sizes (no block-divisibility rule).  dst and src must
+ * not overlap, except that dst == src with src_rows == src_cols == ld_dst == ld_src
+ * is the in-place case, as in the reference (:130-134).  Host or device pointers
+ * (both of the same kind); the transforms never need this (they read columns in
+ * place), it is for callers of the reference's transposes and as a bandwidth
+ * yardstick (tests/bench-transpose.cpp:17-103). */
+int sventt_transpose(uint64_t *dst, const uint64_t *src, uint64_t src_rows,
+                     uint64_t src_cols, uint64_t ld_dst, uint64_t ld_src,
+                     void *stream);
+/* transpose(dst, dim): square, in place (transposition/sve/in-register.hpp:215-375). */
+int sventt_transpose_inplace(uint64_t *dst, uint64_t dim, void *stream);
 
 const char *sventt_last_error(void);
 const char *sventt_version(void);

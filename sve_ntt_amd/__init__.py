@@ -24,7 +24,7 @@ from dataclasses import dataclass
 from . import _lib
 from ._lib import SventtError  # noqa: F401
 
-__all__ = ["Modulus", "NTT", "SventtError", "BASELINE_MODULUS"]
+__all__ = ["Modulus", "NTT", "SventtError", "BASELINE_MODULUS", "transpose", "transpose_inplace"]
 
 
 @dataclass(frozen=True)
@@ -174,3 +174,25 @@ class NTT:
         _lib.check(self._lib.sventt_pointwise_multiply(self._h, d, pa, pb, count,
                                                        _stream_handle(stream)))
         return dst
+
+
+def transpose(dst, src, src_rows: int, src_cols: int, ld_dst: int | None = None,
+              ld_src: int | None = None, stream=None):
+    """``dst[ld_dst*c + r] = src[ld_src*r + c]`` -- the reference's
+    ``Transpose...::transpose(dst, src, src_rows, src_cols, ld_dst, ld_src)``
+    (transposition/sve/in-register.hpp:115-206) as one LDS-tiled HIP kernel."""
+    ld_dst = src_rows if ld_dst is None else ld_dst
+    ld_src = src_cols if ld_src is None else ld_src
+    lib = _lib.load()
+    d, _k1 = _buffer(dst, max(0, ld_dst * (src_cols - 1) + src_rows) if src_cols else 0)
+    s, _k2 = _buffer(src, max(0, ld_src * (src_rows - 1) + src_cols) if src_rows else 0)
+    _lib.check(lib.sventt_transpose(d, s, src_rows, src_cols, ld_dst, ld_src, _stream_handle(stream)))
+    return dst
+
+
+def transpose_inplace(dst, dim: int, stream=None):
+    """Square, in place: ``Transpose...::transpose(dst, dim)`` (in-register.hpp:215-375)."""
+    lib = _lib.load()
+    d, _k = _buffer(dst, dim * dim)
+    _lib.check(lib.sventt_transpose_inplace(d, dim, _stream_handle(stream)))
+    return dst

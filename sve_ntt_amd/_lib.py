@@ -47,6 +47,8 @@ SYMBOLS = {
     "sventt_plan_modulus": (_u64, [_vp]),
     "sventt_plan_describe": (ctypes.c_char_p, [_vp]),
     "sventt_pointwise_multiply": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "sventt_transpose": (_int, [_vp, _vp, _u64, _u64, _u64, _u64, _vp]),
+    "sventt_transpose_inplace": (_int, [_vp, _u64, _vp]),
     "sventt_last_error": (ctypes.c_char_p, []),
     "sventt_version": (ctypes.c_char_p, []),
 }

@@ -301,6 +301,67 @@ int sventt_pointwise_multiply(const sventt_plan *pl, uint64_t *dst, const uint64
   return SVENTT_OK;
 }
 
+int sventt_transpose(uint64_t *dst, const uint64_t *src, uint64_t rows, uint64_t cols,
+                     uint64_t ld_dst, uint64_t ld_src, void *stream_) {
+  if (!dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (ld_src < cols || ld_dst < rows)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "leading dimension shorter than the row it holds");
+  if (rows == 0 || cols == 0) return SVENTT_OK;
+  if ((rows | cols | ld_dst | ld_src) >> 31)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "matrix dimensions must stay below 2^31");
+  if (dst == src) {
+    if (rows == cols && ld_dst == rows && ld_src == cols) return sventt_transpose_inplace(dst, rows, stream_);
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "only a square unpadded matrix can be transposed in place");
+  }
+  const size_t src_elems = (size_t)(ld_src * (rows - 1) + cols), dst_elems = (size_t)(ld_dst * (cols - 1) + rows);
+  if (dst < src + src_elems && src < dst + dst_elems)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "dst and src overlap");
+  if (check_device()) return SVENTT_ERR_NO_DEVICE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool ddst = is_device_pointer(dst), dsrc = is_device_pointer(src);
+  if (ddst && dsrc) {
+    HIP_TRY(launch_transpose(dst, src, rows, cols, ld_dst, ld_src, stream));
+    return SVENTT_OK;
+  }
+  if (ddst != dsrc)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "dst and src must both be device or both be host pointers");
+  // host matrices: stage both through device memory (padding words of dst are preserved)
+  u64 *buf = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), (src_elems + dst_elems) * sizeof(u64)));
+  hipError_t e = hipMemcpyAsync(buf, src, src_elems * sizeof(u64), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess && ld_dst != rows)
+    e = hipMemcpyAsync(buf + src_elems, dst, dst_elems * sizeof(u64), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = launch_transpose(buf + src_elems, buf, rows, cols, ld_dst, ld_src, stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(dst, buf + src_elems, dst_elems * sizeof(u64), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(buf);
+  HIP_TRY(e);
+  return SVENTT_OK;
+}
+
+int sventt_transpose_inplace(uint64_t *dst, uint64_t dim, void *stream_) {
+  if (!dst) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (dim == 0) return SVENTT_OK;
+  if (dim >> 31) return fail(SVENTT_ERR_INVALID_ARGUMENT, "matrix dimensions must stay below 2^31");
+  if (check_device()) return SVENTT_ERR_NO_DEVICE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (is_device_pointer(dst)) {
+    HIP_TRY(launch_transpose_inplace(dst, dim, stream));
+    return SVENTT_OK;
+  }
+  u64 *buf = nullptr;
+  const size_t bytes = (size_t)dim * dim * sizeof(u64);
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), bytes));
+  hipError_t e = hipMemcpyAsync(buf, dst, bytes, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = launch_transpose_inplace(buf, dim, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dst, buf, bytes, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(buf);
+  HIP_TRY(e);
+  return SVENTT_OK;
+}
+
 const char *sventt_last_error(void) { return g_last_error.c_str(); }
 const char *sventt_version(void) { return "sventt-hip 0.1 (gfx950)"; }
 

@@ -171,6 +171,50 @@ static bool check_errors(void) {
   return false;
 }
 
+// the transposition classes keep their static entry points (bench-transpose.cpp:17-103 of the
+// reference checks itself the same way: 2-D iota in, transpose, transpose back)
+static bool check_transposition(void) {
+  constexpr std::uint64_t rows{256}, cols{1024}, pad_src{32}, pad_dst{8};
+  std::vector<std::uint64_t> src((cols + pad_src) * rows - pad_src),
+      dst((rows + pad_dst) * cols - pad_dst, UINT64_C(0x5555555555555555)), back(src.size());
+  for (std::uint64_t r{}; r < rows; ++r) {
+    for (std::uint64_t c{}; c < cols + pad_src && (cols + pad_src) * r + c < src.size(); ++c) {
+      src[(cols + pad_src) * r + c] = c < cols ? UINT64_C(0x0123456789abcdef) + r * cols + c : 0;
+    }
+  }
+  using out_of_place = TransposeParallelSVEInRegisterExplicitBlockingRowFirst<32, 128, 128 + 32, 3>;
+  out_of_place::transpose(dst.data(), src.data(), rows, cols, rows + pad_dst, cols + pad_src);
+  bool ok{true};
+  for (std::uint64_t r{}; r < rows; r += 37) {
+    for (std::uint64_t c{}; c < cols; c += 41) {
+      ok &= dst[(rows + pad_dst) * c + r] == src[(cols + pad_src) * r + c];
+    }
+  }
+  ok &= dst[rows] == UINT64_C(0x5555555555555555);  // padding untouched
+  TransposeParallelSVEInRegister<32, 32>::transpose(back.data(), dst.data(), cols, rows,
+                                                    cols + pad_src, rows + pad_dst);
+  for (std::uint64_t r{}; r < rows; ++r) {
+    for (std::uint64_t c{}; c < cols; ++c) {
+      ok &= back[(cols + pad_src) * r + c] == src[(cols + pad_src) * r + c];
+    }
+  }
+  std::vector<std::uint64_t> square(512 * 512);
+  for (std::uint64_t i{}; i < square.size(); ++i) {
+    square[i] = i;
+  }
+  TransposeParallelSVEInRegisterRowFirst<64, 64, 3>::transpose(square.data(), 512);
+  for (std::uint64_t i{}; i < square.size(); i += 97) {
+    ok &= square[i] == (i % 512) * 512 + i / 512;
+  }
+  try {
+    TransposeParallelSVEInRegister<32, 32>::transpose(back.data(), dst.data(), 48, 64, 64, 48);
+    ok = false;
+  } catch (const std::invalid_argument &) {  // in-register.hpp:121-124 of the reference
+  }
+  std::printf(ok ? "ok transposition classes\n" : "MISMATCH transposition classes\n");
+  return ok;
+}
+
 // compile-time facts the reference's API promises
 static_assert(readme_blocked_six_step::kernel_type::get_m() == (std::uint64_t{1} << 17));
 static_assert(NTT<readme_blocked_six_step::kernel_type>::get_m() == (std::uint64_t{1} << 17));
@@ -202,6 +246,7 @@ int main(int argc, char **argv) {
   ok &= check<test62::four_step, true>("recursive, SVE, four-step");
   ok &= check<big::kernel_type, false>("six-step 2^24 = 2^11 x 2^13");
   ok &= check_errors();
+  ok &= check_transposition();
   std::printf(ok ? "ALL OK\n" : "FAILED\n");
   return ok ? 0 : 1;
 }
