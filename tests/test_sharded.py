@@ -36,7 +36,8 @@ def _run(world: int, env_extra: dict, timeout: int = 300) -> str:
 
 @pytest.mark.parametrize("world,log2n,r_log2,chunks", [(2, 12, 4, 1), (2, 16, 6, 4), (4, 16, 8, 2),
                                                         (2, 18, 3, 4), (4, 20, 6, 8),
-                                                        (2, 22, 6, 4)])  # last: 3 row passes
+                                                        (2, 22, 6, 4),  # 3 row passes
+                                                        (8, 18, 6, 2)])  # the driver's widest node
 def test_sharded_gloo_host_replay(world, log2n, r_log2, chunks):
     out = _run(world, {"ENGINE": "sim", "LOG2N": str(log2n), "R_LOG2": str(r_log2),
                        "CHUNKS": str(chunks)})
