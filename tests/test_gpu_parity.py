@@ -162,6 +162,48 @@ def test_three_pass_sizes_properties(eng, port, log2m):
     assert np.array_equal(host(fa), a)
 
 
+@pytest.mark.parametrize("log2m", [24, 28, 30])
+def test_iota_closed_form_up_to_2p30(eng, log2m):
+    """Sizes no CPU oracle finishes in seconds (BASELINE config #5's 2^30 on one GPU): the
+    harness input of the reference, a[i] = s + i (tests/bench-ntt.cpp:31-33), has a closed form
+    for EVERY output -- X[0] = m s + m(m-1)/2 and X[k] = m / (w^k - 1) for k != 0 (the
+    derivative of the geometric sum) -- so sampled outputs are checked exactly; then the
+    inverse must give the iota back (compared on the device)."""
+    m = 1 << log2m
+    s0 = oracle.INPUT_I1_START
+    src = torch.arange(s0, s0 + m, dtype=torch.int64, device="cuda")
+    dst = torch.full_like(src, 0x5555555555555555)
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    ntt.compute_forward(dst, src)
+    w = pow(G, (P - 1) // m, P)
+    rng = np.random.default_rng(log2m)
+    where = np.unique(np.concatenate([np.arange(64), m - 1 - np.arange(64),
+                                      rng.integers(0, m, size=2048)]))
+    got = dst[torch.from_numpy(where).cuda()].cpu().numpy().view(np.uint64)
+    for j, x in zip(where.tolist(), got.tolist()):
+        k = int(format(j, f"0{log2m}b")[::-1], 2)  # output j holds frequency bitrev(j)
+        want = (m * s0 + m * (m - 1) // 2) % P if k == 0 else m * pow(pow(w, k, P) - 1, -1, P) % P
+        assert x == want, (j, k)
+    del src
+    ntt.compute_inverse(dst)
+    assert torch.equal(dst, torch.arange(s0, s0 + m, dtype=torch.int64, device="cuda"))
+
+
+def test_batched_2p12_full_size_sampled(eng, port):
+    """BASELINE config #4 at full size: 2^16 independent N = 2^12 transforms (2 GiB, in place);
+    97 sampled batches against the oracle, the whole buffer by round trip."""
+    m, batch = 1 << 12, 1 << 16
+    src = torch.randint(0, 1 << 62, (m * batch,), dtype=torch.int64, device="cuda")  # all < p
+    buf = src.clone()
+    ntt = eng.NTT(eng.Modulus(P, G), m, batch=batch)
+    ntt.compute_forward(buf)
+    for b in [0, 1, batch - 1] + list(range(7, batch, 697)):
+        a = host(src[b * m:(b + 1) * m])
+        assert np.array_equal(host(buf[b * m:(b + 1) * m]), port.forward(a, P, G)), b
+    ntt.compute_inverse(buf)
+    assert torch.equal(buf, src)
+
+
 def test_batched_2p12_sampled(eng, port):
     """BASELINE config #4 at reduced batch: 2^10 independent N = 2^12 transforms in place;
     every batch checked against the oracle."""
