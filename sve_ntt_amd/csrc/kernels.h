@@ -9,7 +9,7 @@ namespace sventt_hip {
 
 using KernelEntry = KernelEntryT<hipError_t, hipStream_t>;
 
-const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0);
+const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge);
 
 hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, const Field &f,
                             u64 r2, hipStream_t stream);

@@ -184,8 +184,8 @@ template <class TN> struct HipLauncher {
   }
 };
 
-const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0) {
-  return find_kernel_in_registry<KernelEntry, HipLauncher>(kind, logl, dir, flag, f0);
+const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge) {
+  return find_kernel_in_registry<KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge);
 }
 
 }  // namespace sventt_hip

@@ -70,7 +70,7 @@ int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
   for (size_t i = 0; i < host.size(); ++i) {
     const HostPass &h = host[i];
     DevicePass &d = dev[i];
-    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
+    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
     if (!d.kernel) return fail(SVENTT_ERR_LOGIC, "no kernel instantiated for this pass shape");
     if (d.kernel->f0 != h.f0 || d.kernel->logt != h.logt)
       return fail(SVENTT_ERR_LOGIC, "planner and kernel registry disagree on the tile shape");

@@ -35,6 +35,7 @@ struct HostPass {
   u64 dst_istride = 0, dst_ostride = 0, src_istride = 0, src_ostride = 0;
   u64 grid = 0;
   int f0 = 0, logt = 0;
+  int loge = REG_LOGE;  // elements per thread (log2): REG_LOGE, or FINE_LOGE for small totals
   std::vector<u64> stage, twist_lo, twist_hi;
   u32 twist_shift = 0;
   u64 twist_col_offset = 0;
@@ -47,6 +48,7 @@ struct HostPlan {
   u32 flags = 0;
   u64 r2 = 0;  // 2^128 mod N
   std::vector<HostPass> fwd, inv;
+  bool fine = false;  // E = 4 tiles (registry.h): n * batch too small to fill the chip otherwise
   bool sharded = false;
   int rank = 0, nranks = 1;
   u64 local_cols = 0;
@@ -68,6 +70,7 @@ enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u };
 struct Tuning {
   bool col_slim;
   int max_col_logl;
+  bool fine;  // SVENTT_FINE=0 disables the E = 4 tiles for small transforms
 };
 inline const Tuning &tuning(void) {
   static const Tuning t = [] {
@@ -75,6 +78,8 @@ inline const Tuning &tuning(void) {
     const char *e = std::getenv("SVENTT_COL_SLIM");
     x.col_slim = e ? (std::atoi(e) != 0) : true;  // r01: 2^24 forward column pass 150 -> 138 us
     x.max_col_logl = x.col_slim ? 12 : MAX_COL_LOGL;
+    const char *fe = std::getenv("SVENTT_FINE");
+    x.fine = fe ? (std::atoi(fe) != 0) : true;
     return x;
   }();
   return t;
@@ -143,12 +148,13 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
   ps.dst_istride = ps.src_istride = S;
   ps.dst_ostride = ps.src_ostride = ps.block;
   ps.twist_col_offset = col_offset;
+  ps.loge = pl.fine ? FINE_LOGE : REG_LOGE;
   const bool fold_row_scale = (kind == KIND_ROW) && inverse && flag;
   ps.stage = build_stage_table(f, pl.g, logl, inverse, fold_row_scale ? scale_plain : 1);
   if (fold_row_scale) ps.scale = h_to_montgomery(scale_plain % f.N, f.N);
   u64 tiles;
   if (kind == KIND_COL) {
-    if (logl > tuning().max_col_logl) {
+    if (logl > (pl.fine ? MAX_FINE_COL_LOGL : tuning().max_col_logl)) {
       err = "column pass longer than one workgroup can hold";
       return PLAN_ERR_LOGIC;
     }
@@ -158,7 +164,8 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
     }
     build_twist_tables(f, pl.g, twist_order_log2, inverse, inverse ? scale_plain : 1, ps.twist_lo,
                        ps.twist_hi, ps.twist_shift);
-    ps.f0 = registry_col_f0(logl, ilog2_u64(S), tuning().col_slim);
+    ps.f0 = pl.fine ? registry_fine_col_f0(logl, ilog2_u64(S))
+                    : registry_col_f0(logl, ilog2_u64(S), tuning().col_slim);
     if (ps.f0 < 0 || !is_pow2(S)) {
       // the reference rejects shapes its blocks do not divide the same way
       // (layer/sve/blocked-generic.hpp:111-116)
@@ -169,12 +176,12 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
     const u64 T = 1ull << ps.f0;
     tiles = (pl.total / ps.block) * (S / T);
   } else {
-    if (logl > MAX_ROW_LOGL) {
+    if (logl > (pl.fine ? MAX_FINE_ROW_LOGL : MAX_ROW_LOGL)) {
       err = "row pass longer than one workgroup can hold";
       return PLAN_ERR_LOGIC;
     }
     ps.f0 = 0;
-    ps.logt = registry_row_logt(logl);
+    ps.logt = pl.fine ? registry_fine_row_logt(logl) : registry_row_logt(logl);
     const u64 tile = 1ull << ps.logt;
     tiles = (pl.total + tile - 1) / tile;
   }
@@ -189,8 +196,15 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
 // Split log2(n) into pass lengths: every COL pass <= MAX_COL_LOGL, the final ROW
 // pass <= MAX_ROW_LOGL.  n0_log2 (if non-zero) fixes the first COL pass (the R
 // of the reference's n = R x C six-step, kernel/recursive.hpp:61-75).
-inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row, std::string &err) {
+inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row, std::string &err,
+                        bool fine = false) {
   cols.clear();
+  if (fine) {  // at most two passes; the caller checked that the fine tiles cover the shape
+    const int c = n0_log2 ? (int)n0_log2 : (logn <= MAX_FINE_ROW_LOGL ? 0 : logn / 2);
+    if (c) cols.push_back(c);
+    row = logn - c;
+    return PLAN_OK;
+  }
   int rem = logn;
   if (n0_log2 != 0) {
     if ((int)n0_log2 >= logn || (int)n0_log2 > tuning().max_col_logl) {
@@ -280,7 +294,13 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   if (logn == 0) return PLAN_OK;
   std::vector<int> cols;
   int row = 0;
-  if ((rc = choose_split(logn, n0_log2, cols, row, err))) return rc;
+  // small totals run on the fine (E = 4) tiles, provided they cover the requested split
+  pl.fine = tuning().fine && pl.total <= (1ull << MAX_FINE_TOTAL_LOG2);
+  if (pl.fine && n0_log2 != 0)
+    pl.fine = (int)n0_log2 < logn && (int)n0_log2 <= MAX_FINE_COL_LOGL &&
+              logn - (int)n0_log2 <= MAX_FINE_ROW_LOGL &&
+              registry_fine_col_f0((int)n0_log2, logn - (int)n0_log2) >= 0;
+  if ((rc = choose_split(logn, n0_log2, cols, row, err, pl.fine))) return rc;
   const u64 ninv = h_invmod(n % p, p);
   if (flags & PLAN_FORWARD) {
     int rem = logn;
@@ -503,10 +523,11 @@ inline std::string describe_plan(const HostPlan &pl) {
   for (const HostPass &p : v) {
     if (!d.empty()) d += " | ";
     if (p.kind == KIND_COL)
-      snprintf(buf, sizeof buf, "col 2^%d x T%d (stride %llu)", p.logl, 1 << p.f0,
-               (unsigned long long)p.istride);
+      snprintf(buf, sizeof buf, "col 2^%d x T%d (stride %llu%s)", p.logl, 1 << p.f0,
+               (unsigned long long)p.istride, p.loge == FINE_LOGE ? ", E4" : "");
     else
-      snprintf(buf, sizeof buf, "row 2^%d (tile 2^%d)", p.logl, p.logt);
+      snprintf(buf, sizeof buf, "row 2^%d (tile 2^%d%s)", p.logl, p.logt,
+               p.loge == FINE_LOGE ? ", E4" : "");
     d += buf;
   }
   return d;

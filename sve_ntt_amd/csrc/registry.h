@@ -60,9 +60,38 @@ template <int LOGL, int MODE>
 using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
                             typename DefaultSteps<LOGL>::type>;
 
+// Fine tiles for transforms too small to fill the chip with 2^12-element tiles
+// (n * batch <= 2^19, e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
+// elements per thread in radix-4 steps, 2^8..2^11-element tiles -- four times the
+// workgroups and a quarter of the serial work per thread; these runs are latency
+// bound, not bandwidth bound.
+constexpr int FINE_LOGE = 2;
+constexpr int MAX_FINE_ROW_LOGL = 10;
+constexpr int MAX_FINE_COL_LOGL = 9;
+constexpr int MAX_FINE_TOTAL_LOG2 = 19;
+template <int LOGL> struct FineSteps;
+template <> struct FineSteps<1> { using type = Steps<1>; };
+template <> struct FineSteps<2> { using type = Steps<2>; };
+template <> struct FineSteps<3> { using type = Steps<2, 1>; };
+template <> struct FineSteps<4> { using type = Steps<2, 2>; };
+template <> struct FineSteps<5> { using type = Steps<2, 2, 1>; };
+template <> struct FineSteps<6> { using type = Steps<2, 2, 2>; };
+template <> struct FineSteps<7> { using type = Steps<2, 2, 2, 1>; };
+template <> struct FineSteps<8> { using type = Steps<2, 2, 2, 2>; };
+template <> struct FineSteps<9> { using type = Steps<2, 2, 2, 2, 1>; };
+template <> struct FineSteps<10> { using type = Steps<2, 2, 2, 2, 2>; };
+constexpr int fine_row_logt(int logl) { return logl > 8 ? logl : 8; }
+constexpr int fine_col_f0(int logl) { return logl >= 6 ? 2 : 8 - logl; }
+template <int LOGL, int MODE, bool FLAG>
+using RowTileFine = TileNTT<fine_row_logt(LOGL), 0, LOGL, FINE_LOGE, MODE, FLAG,
+                            typename FineSteps<LOGL>::type>;
+template <int LOGL, int MODE>
+using ColTileFine = TileNTT<LOGL + fine_col_f0(LOGL), fine_col_f0(LOGL), LOGL, FINE_LOGE, MODE, true,
+                            typename FineSteps<LOGL>::type>;
+
 template <class Status, class Stream> struct KernelEntryT {
   int kind, logl, dir, flag;
-  int logt, f0, threads;
+  int logt, f0, threads, loge;
   Status (*launch)(const PassArgs &, u32 grid, Stream);
 };
 
@@ -76,6 +105,7 @@ Entry make_entry(int kind, int dir, int flag) {
   e.logt = TN::LOGT;
   e.f0 = TN::F0;
   e.threads = TN::NT;
+  e.loge = TN::LOGE;
   e.launch = &Launcher<TN>::launch;
   return e;
 }
@@ -92,8 +122,16 @@ Entry make_entry(int kind, int dir, int flag) {
   make_entry<ColTileNarrow<L, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1), \
   make_entry<ColTileNarrow<L, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
 
+#define SVENTT_FINE_ROW_ENTRIES(L)                                                       \
+  make_entry<RowTileFine<L, MODE_FWD, false>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0),   \
+  make_entry<RowTileFine<L, MODE_INV, false>, Entry, Launcher>(KIND_ROW, MODE_INV, 0),   \
+  make_entry<RowTileFine<L, MODE_INV, true>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
+#define SVENTT_FINE_COL_ENTRIES(L)                                              \
+  make_entry<ColTileFine<L, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1), \
+  make_entry<ColTileFine<L, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
+
 template <class Entry, template <class> class Launcher>
-const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int f0) {
+const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int f0, int loge) {
   static const Entry table[] = {
       SVENTT_NARROW_ENTRIES(1), SVENTT_NARROW_ENTRIES(2), SVENTT_NARROW_ENTRIES(3),
       SVENTT_NARROW_ENTRIES(4), SVENTT_NARROW_ENTRIES(5), SVENTT_NARROW_ENTRIES(6),
@@ -113,9 +151,18 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
       make_entry<ColTileSlim<11, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
       make_entry<ColTileSlim<12, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),
       make_entry<ColTileSlim<12, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
+      SVENTT_FINE_ROW_ENTRIES(1), SVENTT_FINE_ROW_ENTRIES(2), SVENTT_FINE_ROW_ENTRIES(3),
+      SVENTT_FINE_ROW_ENTRIES(4), SVENTT_FINE_ROW_ENTRIES(5), SVENTT_FINE_ROW_ENTRIES(6),
+      SVENTT_FINE_ROW_ENTRIES(7), SVENTT_FINE_ROW_ENTRIES(8), SVENTT_FINE_ROW_ENTRIES(9),
+      SVENTT_FINE_ROW_ENTRIES(10),
+      SVENTT_FINE_COL_ENTRIES(1), SVENTT_FINE_COL_ENTRIES(2), SVENTT_FINE_COL_ENTRIES(3),
+      SVENTT_FINE_COL_ENTRIES(4), SVENTT_FINE_COL_ENTRIES(5), SVENTT_FINE_COL_ENTRIES(6),
+      SVENTT_FINE_COL_ENTRIES(7), SVENTT_FINE_COL_ENTRIES(8), SVENTT_FINE_COL_ENTRIES(9),
   };
   for (const Entry &e : table)
-    if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0) return &e;
+    if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0 &&
+        e.loge == loge)
+      return &e;
   return nullptr;
 }
 
@@ -130,5 +177,10 @@ inline int registry_col_f0(int logl, int logs, bool slim = false) {
   return -1;
 }
 inline int registry_row_logt(int logl) { return row_logt(logl); }
+inline int registry_fine_col_f0(int logl, int logs) {
+  if (logl > MAX_FINE_COL_LOGL || logs < fine_col_f0(logl)) return -1;
+  return fine_col_f0(logl);
+}
+inline int registry_fine_row_logt(int logl) { return fine_row_logt(logl); }
 
 }  // namespace sventt_hip

@@ -51,7 +51,7 @@ int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src) {
   const u64 *in = src;
   for (const HostPass &h : passes) {
     const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
+        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
     if (!e || e->f0 != h.f0 || e->logt != h.logt) {
       g_err = "registry mismatch";
       return PLAN_ERR_LOGIC;
@@ -107,7 +107,7 @@ int sim_sharded_rows_pass(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, i
   if (index < 0 || (size_t)index >= passes.size()) return PLAN_ERR_INVALID_ARGUMENT;
   const HostPass &h = passes[(size_t)index];
   const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
+      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
   if (!e) return PLAN_ERR_LOGIC;
   if (dst == src && (h.src_istride != h.dst_istride || h.src_ostride != h.dst_ostride)) {
     g_err = "gather/scatter passes cannot run in place";
@@ -132,7 +132,7 @@ int sim_sharded_chunk(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int r
   const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
   const HostPass &h = (which == 1 && inverse) ? passes.back() : passes.front();
   const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0);
+      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
   if (!e) return PLAN_ERR_LOGIC;
   PassArgs a;
   u32 grid = 0;
@@ -153,7 +153,7 @@ int64_t sim_sharded_tiles_per_block(uint64_t p, uint64_t g, uint64_t n, uint32_t
   return (int64_t)(h.istride >> h.f0);
 }
 
-// Planner introspection: writes up to `cap` entries of (kind, logl, f0, logt, grid) per pass.
+// Planner introspection: writes up to `cap` entries of (kind, logl, f0, logt, grid, loge) per pass.
 int sim_plan_shape(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch, int inverse,
                    int64_t *out, int cap) {
   HostPlan pl;
@@ -163,11 +163,12 @@ int sim_plan_shape(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_
   int k = 0;
   for (const HostPass &h : passes) {
     if (k >= cap) break;
-    out[5 * k + 0] = h.kind;
-    out[5 * k + 1] = h.logl;
-    out[5 * k + 2] = h.f0;
-    out[5 * k + 3] = h.logt;
-    out[5 * k + 4] = (int64_t)h.grid;
+    out[6 * k + 0] = h.kind;
+    out[6 * k + 1] = h.logl;
+    out[6 * k + 2] = h.f0;
+    out[6 * k + 3] = h.logt;
+    out[6 * k + 4] = (int64_t)h.grid;
+    out[6 * k + 5] = h.loge;
     ++k;
   }
   return k;

@@ -88,12 +88,12 @@ def transform(src: np.ndarray, p: int, g: int, n: int, n0_log2: int = 0, batch: 
 
 def plan_shape(p: int, g: int, n: int, n0_log2: int = 0, batch: int = 1, inverse: bool = False):
     L = load()
-    out = (ctypes.c_int64 * 40)()
+    out = (ctypes.c_int64 * 48)()
     k = L.sim_plan_shape(p, g, n, n0_log2, batch, int(inverse), out, 8)
     if k < 0:
         raise SimError((k, L.sim_last_error().decode()))
-    names = ("kind", "logl", "f0", "logt", "grid")
-    return [dict(zip(names, out[5 * i:5 * i + 5])) for i in range(k)]
+    names = ("kind", "logl", "f0", "logt", "grid", "loge")
+    return [dict(zip(names, out[6 * i:6 * i + 6])) for i in range(k)]
 
 
 class SimShardEngine:

@@ -87,6 +87,11 @@ def test_plan_shapes():
     # BASELINE config #2 (README.md:30-32 of the reference): 2^17 = 2^8 x 2^9
     s = simlib.plan_shape(P, G, 1 << 17)
     assert [(x["kind"], x["logl"]) for x in s] == [(1, 8), (0, 9)]
+    # ... on the fine tiles (E = 4): 128 column tiles of 4 columns, one row per tile
+    assert [(x["loge"], x["f0"], x["logt"], x["grid"]) for x in s] == [(2, 2, 10, 128), (2, 0, 9, 256)]
+    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 20))
+    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 12, batch=1 << 8))
+    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 12, batch=1 << 7))
     # BASELINE config #3: 2^24 = 2^11 columns x 2^13 rows, 8-column tiles
     s = simlib.plan_shape(P, G, 1 << 24)
     assert [(x["kind"], x["logl"]) for x in s] == [(1, 11), (0, 13)]
