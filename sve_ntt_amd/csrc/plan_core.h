@@ -71,6 +71,7 @@ struct Tuning {
   bool col_slim;
   int max_col_logl;
   bool fine;  // SVENTT_FINE=0 disables the E = 4 tiles for small transforms
+  int fine_max_total_log2;  // SVENTT_FINE_MAX_LOG2: largest n*batch (log2) that runs on them
 };
 inline const Tuning &tuning(void) {
   static const Tuning t = [] {
@@ -80,6 +81,8 @@ inline const Tuning &tuning(void) {
     x.max_col_logl = x.col_slim ? 12 : MAX_COL_LOGL;
     const char *fe = std::getenv("SVENTT_FINE");
     x.fine = fe ? (std::atoi(fe) != 0) : true;
+    const char *fm = std::getenv("SVENTT_FINE_MAX_LOG2");
+    x.fine_max_total_log2 = fm ? std::atoi(fm) : MAX_FINE_TOTAL_LOG2;
     return x;
   }();
   return t;
@@ -225,8 +228,10 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
   if (row < half) row = half;
   if (row > MAX_ROW_LOGL) row = MAX_ROW_LOGL;
   rem -= row;
+  // (2^25 = 2^12 x 2^13 in two passes beats three: 581 vs 624 us forward, r01)
+  const int max_col = tuning().max_col_logl;
   while (rem > 0) {
-    const int npass = (rem + MAX_COL_LOGL - 1) / MAX_COL_LOGL;
+    const int npass = (rem + max_col - 1) / max_col;
     const int c = (rem + npass - 1) / npass;
     cols.push_back(c);
     rem -= c;
@@ -295,7 +300,10 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   std::vector<int> cols;
   int row = 0;
   // small totals run on the fine (E = 4) tiles, provided they cover the requested split
-  pl.fine = tuning().fine && pl.total <= (1ull << MAX_FINE_TOTAL_LOG2);
+  pl.fine = tuning().fine && pl.total <= (1ull << tuning().fine_max_total_log2) &&
+            logn <= MAX_FINE_COL_LOGL + MAX_FINE_ROW_LOGL &&
+            // 2^12 and 2^13 are one pass on the 2^12/2^13-element tiles, two on the fine ones
+            (n0_log2 != 0 || logn <= MAX_FINE_ROW_LOGL || logn > MAX_ROW_LOGL);
   if (pl.fine && n0_log2 != 0)
     pl.fine = (int)n0_log2 < logn && (int)n0_log2 <= MAX_FINE_COL_LOGL &&
               logn - (int)n0_log2 <= MAX_FINE_ROW_LOGL &&

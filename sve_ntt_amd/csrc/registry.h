@@ -61,14 +61,14 @@ using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
                             typename DefaultSteps<LOGL>::type>;
 
 // Fine tiles for transforms too small to fill the chip with 2^12-element tiles
-// (n * batch <= 2^19, e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
+// (n * batch <= 2^21, e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
 // elements per thread in radix-4 steps, 2^8..2^11-element tiles -- four times the
 // workgroups and a quarter of the serial work per thread; these runs are latency
 // bound, not bandwidth bound.
 constexpr int FINE_LOGE = 2;
-constexpr int MAX_FINE_ROW_LOGL = 10;
-constexpr int MAX_FINE_COL_LOGL = 9;
-constexpr int MAX_FINE_TOTAL_LOG2 = 19;
+constexpr int MAX_FINE_ROW_LOGL = 11;
+constexpr int MAX_FINE_COL_LOGL = 10;
+constexpr int MAX_FINE_TOTAL_LOG2 = 21;
 template <int LOGL> struct FineSteps;
 template <> struct FineSteps<1> { using type = Steps<1>; };
 template <> struct FineSteps<2> { using type = Steps<2>; };
@@ -80,6 +80,7 @@ template <> struct FineSteps<7> { using type = Steps<2, 2, 2, 1>; };
 template <> struct FineSteps<8> { using type = Steps<2, 2, 2, 2>; };
 template <> struct FineSteps<9> { using type = Steps<2, 2, 2, 2, 1>; };
 template <> struct FineSteps<10> { using type = Steps<2, 2, 2, 2, 2>; };
+template <> struct FineSteps<11> { using type = Steps<2, 2, 2, 2, 2, 1>; };
 constexpr int fine_row_logt(int logl) { return logl > 8 ? logl : 8; }
 constexpr int fine_col_f0(int logl) { return logl >= 6 ? 2 : 8 - logl; }
 template <int LOGL, int MODE, bool FLAG>
@@ -154,10 +155,11 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
       SVENTT_FINE_ROW_ENTRIES(1), SVENTT_FINE_ROW_ENTRIES(2), SVENTT_FINE_ROW_ENTRIES(3),
       SVENTT_FINE_ROW_ENTRIES(4), SVENTT_FINE_ROW_ENTRIES(5), SVENTT_FINE_ROW_ENTRIES(6),
       SVENTT_FINE_ROW_ENTRIES(7), SVENTT_FINE_ROW_ENTRIES(8), SVENTT_FINE_ROW_ENTRIES(9),
-      SVENTT_FINE_ROW_ENTRIES(10),
+      SVENTT_FINE_ROW_ENTRIES(10), SVENTT_FINE_ROW_ENTRIES(11),
       SVENTT_FINE_COL_ENTRIES(1), SVENTT_FINE_COL_ENTRIES(2), SVENTT_FINE_COL_ENTRIES(3),
       SVENTT_FINE_COL_ENTRIES(4), SVENTT_FINE_COL_ENTRIES(5), SVENTT_FINE_COL_ENTRIES(6),
       SVENTT_FINE_COL_ENTRIES(7), SVENTT_FINE_COL_ENTRIES(8), SVENTT_FINE_COL_ENTRIES(9),
+      SVENTT_FINE_COL_ENTRIES(10),
   };
   for (const Entry &e : table)
     if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0 &&

@@ -53,11 +53,13 @@ def test_replay_explicit_splits(port, log2m, n0):
 
 
 def test_replay_three_pass_plan(port):
-    """2^25 needs col | col | row; replay a batched-down analogue through n0 to keep it quick,
-    and the real 2^25 shape through the planner only."""
+    """2^25 still fits two passes (2^12 columns of 4), 2^26 needs col | col | row; the shapes
+    through the planner only (a three-pass replay runs in tests/test_sharded.py)."""
     shape = simlib.plan_shape(P, G, 1 << 25)
+    assert [(s["kind"], s["logl"]) for s in shape] == [(1, 12), (0, 13)]
+    shape = simlib.plan_shape(P, G, 1 << 26)
     assert [s["kind"] for s in shape] == [1, 1, 0]
-    assert sum(s["logl"] for s in shape) == 25
+    assert sum(s["logl"] for s in shape) == 26
     shape = simlib.plan_shape(P, G, 1 << 27, inverse=True)
     assert [s["kind"] for s in shape] == [0, 1, 1] and sum(s["logl"] for s in shape) == 27
 
@@ -89,9 +91,12 @@ def test_plan_shapes():
     assert [(x["kind"], x["logl"]) for x in s] == [(1, 8), (0, 9)]
     # ... on the fine tiles (E = 4): 128 column tiles of 4 columns, one row per tile
     assert [(x["loge"], x["f0"], x["logt"], x["grid"]) for x in s] == [(2, 2, 10, 128), (2, 0, 9, 256)]
-    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 20))
-    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 12, batch=1 << 8))
-    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 12, batch=1 << 7))
+    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 21))
+    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 22))
+    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 10, batch=1 << 11))
+    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 10, batch=1 << 12))
+    # 2^12 and 2^13 stay one pass on the big tiles whatever the batch
+    assert [(x["kind"], x["loge"]) for x in simlib.plan_shape(P, G, 1 << 12, batch=4)] == [(0, 4)]
     # BASELINE config #3: 2^24 = 2^11 columns x 2^13 rows, 8-column tiles
     s = simlib.plan_shape(P, G, 1 << 24)
     assert [(x["kind"], x["logl"]) for x in s] == [(1, 11), (0, 13)]
@@ -104,7 +109,7 @@ def test_plan_shapes():
         for inv in (False, True):
             s = simlib.plan_shape(P, G, 1 << logn, inverse=inv)
             assert sum(x["logl"] for x in s) == logn
-            assert all(x["logl"] <= (11 if x["kind"] == 1 else 13) for x in s)
+            assert all(x["logl"] <= (12 if x["kind"] == 1 else 13) for x in s)
 
 
 def test_planner_errors():
