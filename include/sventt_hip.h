@@ -166,6 +166,25 @@ int sventt_pointwise_multiply(const sventt_plan *plan, uint64_t *dst,
                               const uint64_t *a, const uint64_t *b,
                               uint64_t count, void *stream);
 
+/* Domain conversion of `count` device residues: dst[i] = src[i] * 2^64 mod p and back
+ * (PAdic64SVE::to_montgomery / from_montgomery, modmul/sve/p-adic-64.hpp:64-74; the
+ * reference's caller converts a spectrum once so that every later product with it is a
+ * single Montgomery multiplication, examples/magic-series/gaussian-polynomial.hpp:177-179). */
+int sventt_to_montgomery(const sventt_plan *plan, uint64_t *dst, const uint64_t *src,
+                         uint64_t count, void *stream);
+int sventt_from_montgomery(const sventt_plan *plan, uint64_t *dst, const uint64_t *src,
+                           uint64_t count, void *stream);
+
+/* Forward transform with the pointwise product fused into its last pass:
+ *   dst = forward(src) (.) operand        (device pointers)
+ * `operand` holds n*batch residues in MONTGOMERY form (sventt_to_montgomery), indexed
+ * like the bit-reversed output; it may alias src but not dst.  This is the pair
+ * ntt.compute_forward(x); x[j] = multiply_normalize(x[j], operand[j])
+ * of examples/magic-series/gaussian-polynomial.hpp:199-212 without the extra pass over
+ * memory; follow it with sventt_inverse for a cyclic convolution. */
+int sventt_forward_multiply(const sventt_plan *plan, uint64_t *dst, const uint64_t *src,
+                            const uint64_t *operand_montgomery, void *stream);
+
 /* Stand-alone transposition of a matrix of 64-bit words,
  *   dst[ld_dst*c + r] = src[ld_src*r + c],  r < src_rows, c < src_cols,
  * replacing TransposeParallelSVEInRegister<br,bc>::transpose(dst, src, src_rows,

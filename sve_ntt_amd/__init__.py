@@ -175,6 +175,31 @@ class NTT:
                                                        _stream_handle(stream)))
         return dst
 
+    def to_montgomery(self, dst, src=None, stream=None):
+        """dst = src * 2^64 mod p (PAdic64SVE::to_montgomery, p-adic-64.hpp:64-69)."""
+        return self._convert(self._lib.sventt_to_montgomery, dst, src, stream)
+
+    def from_montgomery(self, dst, src=None, stream=None):
+        return self._convert(self._lib.sventt_from_montgomery, dst, src, stream)
+
+    def _convert(self, fn, dst, src, stream):
+        count = self._m * self._batch
+        d, _k1 = _buffer(dst, count)
+        s, _k2 = (d, None) if src is None else _buffer(src, count)
+        _lib.check(fn(self._h, d, s, count, _stream_handle(stream)))
+        return dst
+
+    def compute_forward_multiply(self, dst, src, operand_montgomery, stream=None):
+        """dst = forward(src) * operand element-wise, the product fused into the last pass
+        (the reference's caller does the two separately, gaussian-polynomial.hpp:199-212).
+        ``operand_montgomery``: a spectrum converted once with ``to_montgomery``."""
+        count = self._m * self._batch
+        d, _k0 = _buffer(dst, count)
+        s, _k1 = (d, None) if src is None else _buffer(src, count)
+        o, _k2 = _buffer(operand_montgomery, count)
+        _lib.check(self._lib.sventt_forward_multiply(self._h, d, s, o, _stream_handle(stream)))
+        return dst
+
 
 def transpose(dst, src, src_rows: int, src_cols: int, ld_dst: int | None = None,
               ld_src: int | None = None, stream=None):

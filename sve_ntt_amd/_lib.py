@@ -47,6 +47,9 @@ SYMBOLS = {
     "sventt_plan_modulus": (_u64, [_vp]),
     "sventt_plan_describe": (ctypes.c_char_p, [_vp]),
     "sventt_pointwise_multiply": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "sventt_to_montgomery": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sventt_from_montgomery": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sventt_forward_multiply": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sventt_transpose": (_int, [_vp, _vp, _u64, _u64, _u64, _u64, _vp]),
     "sventt_transpose_inplace": (_int, [_vp, _u64, _vp]),
     "sventt_last_error": (ctypes.c_char_p, []),

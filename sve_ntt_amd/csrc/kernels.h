@@ -14,6 +14,10 @@ const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, in
 hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, const Field &f,
                             u64 r2, hipStream_t stream);
 
+// dst[i] = montmul(a[i], b ? b[i] : c)
+hipError_t launch_montmul(u64 *dst, const u64 *a, const u64 *b, u64 c, u64 count, const Field &f,
+                          hipStream_t stream);
+
 // dst[ld_dst*c + r] = src[ld_src*r + c], r < rows, c < cols (out of place)
 hipError_t launch_transpose(u64 *dst, const u64 *src, u64 rows, u64 cols, u64 ld_dst, u64 ld_src,
                             hipStream_t stream);

@@ -77,6 +77,24 @@ hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, con
   return hipGetLastError();
 }
 
+// dst[i] = montmul(a[i], b ? b[i] : c): domain conversions (c = R^2 -> to Montgomery form,
+// c = 1 -> back; modmul/sve/p-adic-64.hpp:64-74 of the reference) and the length-1 case
+// of the fused forward-multiply.
+__global__ __launch_bounds__(256) void montmul_kernel(u64 *dst, const u64 *a, const u64 *b, u64 c,
+                                                      u64 count, Field f) {
+  for (u64 i = blockIdx.x * 256ull + threadIdx.x; i < count; i += (u64)gridDim.x * 256ull)
+    dst[i] = montmul(a[i], b ? b[i] : c, f);
+}
+
+hipError_t launch_montmul(u64 *dst, const u64 *a, const u64 *b, u64 c, u64 count, const Field &f,
+                          hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  u64 blocks = (count + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(montmul_kernel, dim3((u32)blocks), dim3(256), 0, stream, dst, a, b, c, count, f);
+  return hipGetLastError();
+}
+
 // ---- stand-alone transposition ---------------------------------------------------
 // dst[ld_dst*c + r] = src[ld_src*r + c]: the GPU counterpart of the reference's
 // transposition kernels (transposition/sve/in-register.hpp:111-206, in place :215-375).

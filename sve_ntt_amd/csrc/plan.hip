@@ -33,6 +33,7 @@ int fail(int code, const std::string &msg) {
 
 struct DevicePass {
   const KernelEntry *kernel = nullptr;
+  const KernelEntry *kernel_multiply = nullptr;  // final forward ROW pass with the product epilogue
   u64 *stage = nullptr, *twist_lo = nullptr, *twist_hi = nullptr;
 };
 
@@ -74,6 +75,8 @@ int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
     if (!d.kernel) return fail(SVENTT_ERR_LOGIC, "no kernel instantiated for this pass shape");
     if (d.kernel->f0 != h.f0 || d.kernel->logt != h.logt)
       return fail(SVENTT_ERR_LOGIC, "planner and kernel registry disagree on the tile shape");
+    if (h.kind == KIND_ROW && !h.inverse && !h.flag)
+      d.kernel_multiply = find_kernel(KIND_ROW, h.logl, MODE_FWD, 1, h.f0, h.loge);
     int rc;
     if ((rc = upload(h.stage, d.stage))) return rc;
     if ((rc = upload(h.twist_lo, d.twist_lo))) return rc;
@@ -299,6 +302,54 @@ int sventt_pointwise_multiply(const sventt_plan *pl, uint64_t *dst, const uint64
   HIP_TRY(launch_pointwise(dst, a, b, count, pl->host.f, pl->host.r2,
                            static_cast<hipStream_t>(stream)));
   return SVENTT_OK;
+}
+
+int sventt_forward_multiply(const sventt_plan *pl, uint64_t *dst, const uint64_t *src,
+                            const uint64_t *operand, void *stream_) {
+  if (!pl || !dst || !src || !operand) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (pl->host.sharded) return fail(SVENTT_ERR_LOGIC, "not available on sharded plans");
+  if (!(pl->host.flags & PLAN_FORWARD)) return fail(SVENTT_ERR_LOGIC, "plan was created without SVENTT_FORWARD");
+  if (!is_device_pointer(dst) || !is_device_pointer(src) || !is_device_pointer(operand))
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "the fused forward-multiply takes device pointers");
+  if (operand == dst) return fail(SVENTT_ERR_INVALID_ARGUMENT, "operand must not alias dst");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (pl->host.n == 1) {
+    HIP_TRY(launch_montmul(dst, src, operand, 0, pl->host.total, pl->host.f, stream));
+    return SVENTT_OK;
+  }
+  const size_t npass = pl->fwd.size();
+  const u64 *in = src;
+  for (size_t i = 0; i + 1 < npass; ++i) {
+    int rc = run_pass(pl, false, i, dst, in, stream);
+    if (rc) return rc;
+    in = dst;
+  }
+  const HostPass &h = pl->host.fwd[npass - 1];
+  const DevicePass &d = pl->fwd[npass - 1];
+  if (!d.kernel_multiply) return fail(SVENTT_ERR_LOGIC, "no fused kernel for this plan's final pass");
+  PassArgs a = make_args(pl->host, h, dst, in, d.stage, d.twist_lo, d.twist_hi);
+  a.epilogue = operand;
+  HIP_TRY(d.kernel_multiply->launch(a, (u32)h.grid, stream));
+  return SVENTT_OK;
+}
+
+static int convert_domain(const sventt_plan *pl, uint64_t *dst, const uint64_t *src, uint64_t count,
+                          u64 factor, void *stream) {
+  if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!is_device_pointer(dst) || !is_device_pointer(src))
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "domain conversion takes device pointers");
+  HIP_TRY(launch_montmul(dst, src, nullptr, factor, count, pl->host.f, static_cast<hipStream_t>(stream)));
+  return SVENTT_OK;
+}
+
+int sventt_to_montgomery(const sventt_plan *pl, uint64_t *dst, const uint64_t *src, uint64_t count,
+                         void *stream) {
+  return convert_domain(pl, dst, src, count, pl ? pl->host.r2 : 0, stream);
+}
+
+int sventt_from_montgomery(const sventt_plan *pl, uint64_t *dst, const uint64_t *src, uint64_t count,
+                           void *stream) {
+  return convert_domain(pl, dst, src, count, 1, stream);
 }
 
 int sventt_transpose(uint64_t *dst, const uint64_t *src, uint64_t rows, uint64_t cols,

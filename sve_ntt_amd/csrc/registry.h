@@ -113,6 +113,7 @@ Entry make_entry(int kind, int dir, int flag) {
 
 #define SVENTT_ROW_ENTRIES(L)                                                        \
   make_entry<RowTile<L, MODE_FWD, false>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0),   \
+  make_entry<RowTile<L, MODE_FWD, true>, Entry, Launcher>(KIND_ROW, MODE_FWD, 1),    \
   make_entry<RowTile<L, MODE_INV, false>, Entry, Launcher>(KIND_ROW, MODE_INV, 0),   \
   make_entry<RowTile<L, MODE_INV, true>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
 #define SVENTT_COL_ENTRIES(L)                                             \
@@ -125,6 +126,7 @@ Entry make_entry(int kind, int dir, int flag) {
 
 #define SVENTT_FINE_ROW_ENTRIES(L)                                                       \
   make_entry<RowTileFine<L, MODE_FWD, false>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0),   \
+  make_entry<RowTileFine<L, MODE_FWD, true>, Entry, Launcher>(KIND_ROW, MODE_FWD, 1),    \
   make_entry<RowTileFine<L, MODE_INV, false>, Entry, Launcher>(KIND_ROW, MODE_INV, 0),   \
   make_entry<RowTileFine<L, MODE_INV, true>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
 #define SVENTT_FINE_COL_ENTRIES(L)                                              \

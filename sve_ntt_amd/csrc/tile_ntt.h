@@ -68,6 +68,8 @@ struct PassArgs {
   u32 twist_shift;
   u64 twist_col_offset; // added to the column index (rank offset of a sharded column pass)
   u64 scale;            // ROW inverse with FLAG: L^{-1} (Montgomery form)
+  const u64 *epilogue;  // ROW forward with FLAG: dst[i] = X[i] * epilogue[i] (operand in
+                        // Montgomery form), the pointwise product a convolution does next
 };
 
 template <int... KS> struct Steps {
@@ -98,7 +100,8 @@ F64_HD u32 bitrev32(u32 x) {
 }
 
 // FLAG: COL tiles -> apply the pass twist (store side forward, load side inverse);
-//       ROW inverse tiles -> fold the 1/L scaling into the top stage.
+//       ROW inverse tiles -> fold the 1/L scaling into the top stage;
+//       ROW forward tiles -> multiply by PassArgs::epilogue on the way out.
 template <int LOGT_, int F0_, int LOGL_, int LOGE_, int MODE_, bool FLAG_, class STEPS_>
 struct TileNTT {
   static constexpr int LOGT = LOGT_, F0 = F0_, LOGL = LOGL_, LOGE = LOGE_, MODE = MODE_;
@@ -280,6 +283,15 @@ struct TileNTT {
           for (int v = 0; v < R; ++v) tw[v] = twist_lookup(a, tw_e0 + tw_col * twist_bv(v, LO));
 #pragma unroll
           for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], tw[v], a.f);
+        }
+        if constexpr (!COL && FLAG && MODE == MODE_FWD) {
+          const u64 *e0 = a.epilogue + gaddr(a, t, I0);
+          u64 op[R];
+#pragma unroll
+          for (int v = 0; v < R; ++v)
+            op[v] = in_range(a, t, I0 | ((u32)v << lo)) ? e0[(u64)v * vstride] : 0;
+#pragma unroll
+          for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], op[v], a.f);
         }
 #pragma unroll
         for (int v = 0; v < R; ++v)

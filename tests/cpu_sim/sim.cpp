@@ -42,21 +42,26 @@ using SimEntry = KernelEntryT<int, int>;
 
 thread_local std::string g_err;
 
-int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src) {
+// `epilogue` (forward only): the fused product of sventt_forward_multiply -- the final
+// ROW pass runs as its FLAG variant with PassArgs::epilogue set.
+int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src, const u64 *epilogue = nullptr) {
   const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
   if (pl.n == 1) {
-    if (dst != src) memcpy(dst, src, pl.total * sizeof(u64));
+    for (u64 i = 0; i < pl.total; ++i) dst[i] = epilogue ? montmul(src[i], epilogue[i], pl.f) : src[i];
     return 0;
   }
   const u64 *in = src;
-  for (const HostPass &h : passes) {
+  for (size_t i = 0; i < passes.size(); ++i) {
+    const HostPass &h = passes[i];
+    const bool fused = epilogue && i + 1 == passes.size();
     const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
-    if (!e || e->f0 != h.f0 || e->logt != h.logt) {
+        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, (h.flag || fused) ? 1 : 0, h.f0, h.loge);
+    if (!e || e->f0 != h.f0 || e->logt != h.logt || (fused && h.kind != KIND_ROW)) {
       g_err = "registry mismatch";
       return PLAN_ERR_LOGIC;
     }
-    const PassArgs a = make_args(pl, h, dst, in, h.stage.data(), h.twist_lo.data(), h.twist_hi.data());
+    PassArgs a = make_args(pl, h, dst, in, h.stage.data(), h.twist_lo.data(), h.twist_hi.data());
+    if (fused) a.epilogue = epilogue;
     e->launch(a, (u32)h.grid, 0);
     in = dst;
   }
@@ -76,6 +81,16 @@ int sim_transform(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t
   int rc = build_plan(pl, p, g, n, n0_log2, batch, inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
   if (rc) return rc;
   return run_plan(pl, inverse != 0, dst, src);
+}
+
+// sventt_forward_multiply: forward transform with the pointwise product (operand in
+// Montgomery form) fused into the last pass.
+int sim_forward_multiply(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch,
+                         uint64_t *dst, const uint64_t *src, const uint64_t *operand) {
+  HostPlan pl;
+  int rc = build_plan(pl, p, g, n, n0_log2, batch, PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  return run_plan(pl, false, dst, src, operand);
 }
 
 // One rank's column pass of the sharded six-step (same arguments as sventt_sharded_columns).

@@ -11,8 +11,9 @@ formulation written for this test suite (block-wise power-series division with a
 Newton-iterated reciprocal); only the call pattern on the transform is shared.
 
 TEST-ONLY.  The transform is injected as a backend:
-  * EngineBackend -- sve_ntt_amd.NTT on the GPU (forward / pointwise_multiply /
-    inverse through the C ABI), the thing under test;
+  * EngineBackend -- sve_ntt_amd.NTT on the GPU (forward / pointwise_multiply / inverse
+    in the Newton iteration, the fused forward_multiply in the block loop, through the
+    C ABI), the thing under test;
   * OracleBackend -- the CPU oracle, used by the no-GPU tier to validate this file
     itself against the same known answers.
 """
@@ -57,6 +58,12 @@ class OracleBackend:
     def inverse(self, fa) -> np.ndarray:
         return self.port.inverse(fa, self.p, self.g)
 
+    def prepare(self, fa):
+        return fa
+
+    def forward_times(self, a: np.ndarray, prepared):
+        return self.pointwise(self.forward(a), prepared)
+
 
 class EngineBackend:
     """The same three operations on the GPU; spectra stay resident as torch tensors."""
@@ -85,6 +92,19 @@ class EngineBackend:
         out = self.torch.empty_like(fa)
         self._plan(fa.numel()).compute_inverse(out, fa)
         return out.cpu().numpy().view(U64)
+
+    def prepare(self, fa):
+        """A spectrum that will multiply many transforms: to Montgomery form once, as the
+        reference's caller does (gaussian-polynomial.hpp:177-179)."""
+        out = self.torch.empty_like(fa)
+        self._plan(fa.numel()).to_montgomery(out, fa)
+        return out
+
+    def forward_times(self, a: np.ndarray, prepared):
+        """forward(a) (.) spectrum with the product fused into the transform's last pass."""
+        t = self.torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+        self._plan(a.size).compute_forward_multiply(t, None, prepared)
+        return t
 
 
 def _padded(a: np.ndarray, n: int) -> np.ndarray:
@@ -120,15 +140,15 @@ def gaussian_binomial_coefficient(be, n: int, k: int, d: int, p: int, ntt_len: i
     if den.size > block:
         raise ValueError("NTT length is too small")
     num = one_minus_q_powers(range(n - k + 1, n + 1), d + 1, p)
-    f_den = be.forward(_padded(den, ntt_len))
-    f_rec = be.forward(_padded(reciprocal(be, den, block, p), ntt_len))
+    f_den = be.prepare(be.forward(_padded(den, ntt_len)))
+    f_rec = be.prepare(be.forward(_padded(reciprocal(be, den, block, p), ntt_len)))
     rem = _padded(num[:block], block)
     t = 0
     while True:
-        quot = be.inverse(be.pointwise(be.forward(_padded(rem, ntt_len)), f_rec))[:block]
+        quot = be.inverse(be.forward_times(_padded(rem, ntt_len), f_rec))[:block]
         if d < (t + 1) * block:
             return int(quot[d - t * block])
-        back = be.inverse(be.pointwise(be.forward(_padded(quot, ntt_len)), f_den))
+        back = be.inverse(be.forward_times(_padded(quot, ntt_len), f_den))
         # quot * den reproduces the window exactly; what spills over is owed by the next one
         if not np.array_equal(back[:block], rem):
             raise AssertionError("block division lost the remainder invariant")

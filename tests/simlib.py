@@ -39,6 +39,8 @@ def load() -> ctypes.CDLL:
         L.sim_last_error.restype = ctypes.c_char_p
         L.sim_transform.restype = _int
         L.sim_transform.argtypes = [_u64, _u64, _u64, _u32, _u64, _int, _p64, _p64]
+        L.sim_forward_multiply.restype = _int
+        L.sim_forward_multiply.argtypes = [_u64, _u64, _u64, _u32, _u64, _p64, _p64, _p64]
         L.sim_sharded_columns.restype = _int
         L.sim_sharded_columns.argtypes = [_u64, _u64, _u64, _u32, _int, _int, _int, _p64, _p64]
         L.sim_sharded_rows_num_passes.restype = _int
@@ -81,6 +83,18 @@ def transform(src: np.ndarray, p: int, g: int, n: int, n0_log2: int = 0, batch: 
     src = np.ascontiguousarray(src, dtype=np.uint64)
     dst = np.full_like(src, 0x5555555555555555)
     rc = L.sim_transform(p, g, n, n0_log2, batch, int(inverse), _ptr(dst), _ptr(src))
+    if rc != 0:
+        raise SimError((rc, L.sim_last_error().decode()))
+    return dst
+
+
+def forward_multiply(src: np.ndarray, operand_montgomery: np.ndarray, p: int, g: int, n: int,
+                     n0_log2: int = 0, batch: int = 1) -> np.ndarray:
+    L = load()
+    src = np.ascontiguousarray(src, dtype=np.uint64)
+    op = np.ascontiguousarray(operand_montgomery, dtype=np.uint64)
+    dst = np.full_like(src, 0x5555555555555555)
+    rc = L.sim_forward_multiply(p, g, n, n0_log2, batch, _ptr(dst), _ptr(src), _ptr(op))
     if rc != 0:
         raise SimError((rc, L.sim_last_error().decode()))
     return dst

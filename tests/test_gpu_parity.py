@@ -290,6 +290,72 @@ def test_linearity_and_convolution(eng, port):
         assert int(got[k]) == want
 
 
+@pytest.mark.parametrize("log2m,batch", [(0, 5), (3, 1), (10, 7), (12, 1), (13, 2), (17, 1), (20, 1), (22, 1)])
+def test_forward_multiply_fused(eng, port, log2m, batch):
+    """sventt_forward_multiply == compute_forward followed by pointwise_multiply (and both ==
+    the oracle's forward times the operand); to/from_montgomery round trip."""
+    m = 1 << log2m
+    src = port.fill_splitmix(m * batch, 11 + log2m, P)
+    operand = port.fill_splitmix(m * batch, 13 + log2m, P)
+    ntt = eng.NTT(eng.Modulus(P, G), m, batch=batch)
+    s, o = dev(src), dev(operand)
+    om = torch.empty_like(o)
+    ntt.to_montgomery(om, o)
+    assert int(host(om)[0]) == port.to_montgomery(int(operand[0]), P)
+    back = torch.empty_like(o)
+    ntt.from_montgomery(back, om)
+    assert torch.equal(back, o)
+    fused = torch.full_like(s, 0x5555555555555555)
+    ntt.compute_forward_multiply(fused, s, om)
+    two_step = torch.empty_like(s)
+    ntt.compute_forward(two_step, s)
+    ntt.pointwise_multiply(two_step, two_step, o)
+    assert torch.equal(fused, two_step)
+    f = port.forward(src[:m], P, G) if m > 1 else src[:1]
+    want = (f.astype(object) * operand[:m].astype(object)) % P
+    assert np.array_equal(host(fused)[:m], np.array(want, dtype=np.uint64))
+    inplace = s.clone()
+    ntt.compute_forward_multiply(inplace, None, om)  # in place
+    assert torch.equal(inplace, fused)
+    with pytest.raises(ValueError):
+        ntt.compute_forward_multiply(fused, s, fused)  # operand aliases dst
+
+
+def test_distinct_plans_on_concurrent_host_threads(eng, port):
+    """Boundary contract (SURVEY.md 8b "Threading"): compute_* are re-entrant across plans.
+    Four host threads, each with its own plan, stream and length, transform concurrently."""
+    import threading
+    shapes = [(1 << 12, 8), (1 << 16, 1), (1 << 20, 1), (1 << 13, 3)]
+    results, errors = {}, []
+
+    def work(i, m, batch):
+        try:
+            src = port.fill_splitmix(m * batch, 100 + i, P)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                ntt = eng.NTT(eng.Modulus(P, G), m, batch=batch)
+                s = dev(src)
+                d = torch.empty_like(s)
+                for _ in range(20):
+                    ntt.compute_forward(d, s, stream=stream)
+                    ntt.compute_inverse(d, stream=stream)
+                    ntt.compute_forward(d, stream=stream)
+                stream.synchronize()
+            results[i] = (src, host(d), m, batch)
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i, m, b)) for i, (m, b) in enumerate(shapes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (src, got, m, batch) in results.items():
+        for b in range(batch):
+            assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G)), (i, b)
+
+
 def test_error_behaviour(eng):
     with pytest.raises(ValueError):  # std::invalid_argument
         eng.NTT(eng.Modulus(P, G), 12)

@@ -74,6 +74,21 @@ def test_replay_ragged_batches(port, m, batch):
     assert np.array_equal(simlib.transform(got, P, G, m, batch=batch, inverse=True), src)
 
 
+@pytest.mark.parametrize("m,batch,n0", [(1, 3, 0), (2, 1, 0), (64, 5, 0), (1 << 11, 1, 0), (1 << 12, 3, 0),
+                                        (1 << 13, 1, 0), (1 << 14, 1, 0), (1 << 14, 1, 3), (1 << 16, 2, 0)])
+def test_replay_forward_multiply(port, m, batch, n0):
+    """sventt_forward_multiply: forward transform with the pointwise product (Montgomery-form
+    operand) fused into the final pass == oracle forward, then an element-wise product."""
+    src = port.fill_splitmix(m * batch, m + batch, P)
+    operand = port.fill_splitmix(m * batch, 3 * m + batch, P)
+    op_mont = np.array([port.to_montgomery(int(x), P) for x in operand], dtype=np.uint64)
+    got = simlib.forward_multiply(src, op_mont, P, G, m, n0_log2=n0, batch=batch)
+    for b in range(batch):
+        f = port.forward(src[b * m:(b + 1) * m], P, G)
+        want = (f.astype(object) * operand[b * m:(b + 1) * m].astype(object)) % P
+        assert np.array_equal(got[b * m:(b + 1) * m], np.array(want, dtype=np.uint64)), b
+
+
 @pytest.mark.parametrize("N,g", [(oracle.TEST62_P, 3), (oracle.GOLDILOCKS_P, 7),
                                  (0x0C40000000000001, 5), (0x0002580000000001, 11)])
 def test_replay_other_moduli(port, N, g):
