@@ -74,6 +74,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm", type=int, default=-1,
+                    help="untimed clock-ramp steps before the warmup (default 1500, sharded 300)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,14 +139,23 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The GPU ramps its clocks over the first tens of milliseconds of load (from idle the
+    # first ~100 transforms run at ~300 us instead of ~230 us, tools/clock_ramp.py): bring
+    # it to its steady state with a fixed number of untimed steps (the same count on every
+    # rank -- a step contains collectives when sharded) before the W warmup steps.
+    for _ in range(args.prewarm if args.prewarm >= 0 else (1500 if world == 1 else 300)):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(npass + 1)]
-              for _ in range(args.steps)]
+    # per-pass HIP events on every 4th step of the timed region (an event pair around every
+    # launch costs 3-7 % of the step, tools/event_overhead.py; a quarter of them ~1 %)
+    sampled = [k for k in range(args.steps) if k % 4 == 0]
+    events = {k: [torch.cuda.Event(enable_timing=True) for _ in range(npass + 1)] for k in sampled}
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step(events.get(k))
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -154,7 +165,7 @@ def main() -> None:
 
     # per-phase device time from the HIP events of the timed region
     phase_ms = [float(np.mean([events[k][i].elapsed_time(events[k][i + 1])
-                               for k in range(args.steps)])) for i in range(npass)]
+                               for k in sampled])) for i in range(npass)]
     names = desc.split(" | ")
     if len(names) != npass:
         names = [f"phase {i}" for i in range(npass)]
@@ -202,6 +213,7 @@ def main() -> None:
             "algorithmic_bytes_per_launch": dom_bytes,
             "kernel_ms": phase_ms[dom],
             "all_phases_ms": [[names[i], phase_ms[i]] for i in range(npass)],
+            "event_sampled_steps": len(sampled),
             "transform_device_ms": device_ms,
             "transform_frac": (ALGO_BYTES_PER_ELEMENT * n_local / (device_ms * 1e-3)) / HBM_PEAK,
         },

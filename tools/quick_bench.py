@@ -44,7 +44,7 @@ for inverse in (False, True):
     npass = ntt.num_passes(inverse)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(npass + 1)] for _ in range(iters)]
     a, b = (dst, src) if not inverse else (back, dst)
-    for _ in range(5):
+    for _ in range(max(5, min(1000, (1 << 33) // (n * batch)))):  # clock ramp, tools/clock_ramp.py
         for i in range(npass):
             ntt.run_pass(inverse, i, a, b if i == 0 else None)
     torch.cuda.synchronize()
