@@ -72,6 +72,7 @@ struct Tuning {
   int max_col_logl;
   bool fine;  // SVENTT_FINE=0 disables the E = 4 tiles for small transforms
   int fine_max_total_log2;  // SVENTT_FINE_MAX_LOG2: largest n*batch (log2) that runs on them
+  int twist_lo_log2;        // SVENTT_TWIST_LO_LOG2: cap on the low twist table (0: balanced split)
 };
 inline const Tuning &tuning(void) {
   static const Tuning t = [] {
@@ -83,6 +84,11 @@ inline const Tuning &tuning(void) {
     x.fine = fe ? (std::atoi(fe) != 0) : true;
     const char *fm = std::getenv("SVENTT_FINE_MAX_LOG2");
     x.fine_max_total_log2 = fm ? std::atoi(fm) : MAX_FINE_TOTAL_LOG2;
+    const char *tl = std::getenv("SVENTT_TWIST_LO_LOG2");
+    // r01: a low table of 2^10 entries (8 KiB) stays in the vector L1 whatever the lanes ask
+    // for; the balanced split (2^12..2^14 entries) cost the column pass 2 % at M = 2^24 and
+    // 12 % at M = 2^27 (sharded, 8 ranks)
+    x.twist_lo_log2 = tl ? std::atoi(tl) : 10;
     return x;
   }();
   return t;
@@ -123,6 +129,7 @@ inline void build_twist_tables(const Field &f, u64 gen, int logm, bool inverse, 
   u64 w = h_powmod(gen, (N - 1) >> logm, N);
   if (inverse) w = h_invmod(w, N);
   shift = (u32)((logm + 1) / 2);
+  if (tuning().twist_lo_log2 > 0 && (int)shift > tuning().twist_lo_log2) shift = (u32)tuning().twist_lo_log2;
   lo.resize(1ull << shift);
   hi.resize(1ull << (logm - (int)shift));
   u64 cur = 1;

@@ -28,12 +28,15 @@ for world in (2, 4, 8):
     def run(ev=None):
         k = 0
         if ev: ev[k].record()
-        e.columns(False, work, src); k += 1
+        e.columns_chunk(False, work, src, 0, 1); k += 1
         if ev: ev[k].record()
-        for i in range(e.rows_passes):
-            e.rows_pass(False, i, out, work if i == 0 else out); k += 1
+        # (the all-to-all would run here; the gather pass reads `work` as if received)
+        e.exchange_side_chunk(False, out, work, 0, 1); k += 1
+        if ev: ev[k].record()
+        for i in range(1, e.rows_passes):
+            e.rows_pass(False, i, out, out); k += 1
             if ev: ev[k].record()
-    for _ in range(3):
+    for _ in range(300):  # steady-state clocks, tools/clock_ramp.py
         run()
     torch.cuda.synchronize()
     nph = 1 + e.rows_passes
