@@ -356,6 +356,24 @@ def test_distinct_plans_on_concurrent_host_threads(eng, port):
             assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G)), (i, b)
 
 
+def test_plan_lifecycle_returns_device_memory(eng):
+    """Creating and destroying plans (device twiddle tables, staging buffer) must not leak."""
+    def cycle(count):
+        for i in range(count):
+            ntt = eng.NTT(eng.Modulus(P, G), 1 << (10 + i % 12), batch=1 + i % 3)
+            if i % 7 == 0:  # host-pointer call allocates the plan's staging buffer
+                a = np.arange(ntt.get_m() * ntt.batch, dtype=np.uint64)
+                ntt.compute_forward(a)
+            del ntt
+    cycle(20)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(300)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)
+
+
 def test_error_behaviour(eng):
     with pytest.raises(ValueError):  # std::invalid_argument
         eng.NTT(eng.Modulus(P, G), 12)
