@@ -97,6 +97,28 @@ public:
   }
 
   void compute_inverse(std::uint64_t *const dst) const { compute_inverse(dst, dst); }
+
+  // ---- extensions for data that stays on the device (not in the reference's wrapper) ----
+  // What its caller does around the transforms (examples/magic-series/
+  // gaussian-polynomial.hpp:176-212): convert a spectrum to Montgomery form once, then
+  // multiply every forward transform by it.  All pointers are device pointers.
+
+  // dst[i] = src[i] * 2^64 mod N over get_m() elements (PAdic64SVE::to_montgomery)
+  void to_montgomery(std::uint64_t *const dst, const std::uint64_t *const src) const {
+    detail::throw_on_error(sventt_to_montgomery(plan, dst, src, get_m(), nullptr));
+  }
+
+  // dst = forward(src) (.) operand_montgomery, the product fused into the last pass
+  void compute_forward_multiply(std::uint64_t *const dst, const std::uint64_t *const src,
+                                const std::uint64_t *const operand_montgomery) const {
+    detail::throw_on_error(sventt_forward_multiply(plan, dst, src, operand_montgomery, nullptr));
+  }
+
+  // dst[i] = a[i] * b[i] mod N (plain residues) over get_m() elements
+  void pointwise_multiply(std::uint64_t *const dst, const std::uint64_t *const a,
+                          const std::uint64_t *const b) const {
+    detail::throw_on_error(sventt_pointwise_multiply(plan, dst, a, b, get_m(), nullptr));
+  }
 };
 
 } // namespace sventt

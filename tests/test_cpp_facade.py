@@ -27,6 +27,43 @@ def _build():
     assert "warning" not in r.stderr, r.stderr[-3000:]
 
 
+DEV_EXE = os.path.join(ROOT, "tests", "cpp", "device_convolution")
+
+
+def _build_device_harness():
+    """C++ host code on hipMalloc'd buffers (HIP runtime for memory and events only)."""
+    import oracle
+    oracle.build()
+    from sve_ntt_amd import build as hip_build
+    hip_build.build()
+    cmd = ["g++", "-std=c++20", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(ROOT, "tests", "cpp", "device_convolution.cpp"),
+           "-L" + os.path.join(ROOT, "sve_ntt_amd"), "-lsventt_hip",
+           "-L" + os.path.join(ROOT, "oracle"), "-lntt_oracle", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "sve_ntt_amd"),
+           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath,/opt/rocm/lib", "-o", DEV_EXE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_device_pointer_harness_compiles_and_links():
+    _build_device_harness()
+    r = subprocess.run([DEV_EXE, "--compile-only-check"], capture_output=True, text=True)
+    assert r.returncode == 0 and "compiled and linked" in r.stdout
+
+
+@pytest.mark.gpu
+def test_device_pointer_convolution_in_cpp():
+    """tests/cpp/device_convolution.cpp: cyclic convolutions on device pointers == oracle;
+    N = 2^24 forward/inverse closed forms; prints the C++-side timing of the BASELINE config."""
+    _build_device_harness()
+    r = subprocess.run([DEV_EXE], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ALL OK" in r.stdout and "MISMATCH" not in r.stdout
+
+
 def test_facade_compiles_and_links():
     _build()
     r = subprocess.run([EXE, "--compile-only-check"], capture_output=True, text=True)
