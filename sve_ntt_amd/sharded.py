@@ -201,3 +201,39 @@ class ShardedNTT:
             e.columns_chunk(True, dst, self._piece(self._back, k), k, K)
         self._mark(events, 2 + n_in_place)
         return dst
+
+
+def batch_partition(batch: int, world: int, rank: int) -> tuple[int, int]:
+    """(first transform, count) of rank ``rank`` when ``batch`` independent transforms are
+    dealt over ``world`` ranks in contiguous, near-equal shares (the first ``batch % world``
+    ranks take one more)."""
+    if batch < 0 or world < 1 or not 0 <= rank < world:
+        raise ValueError("bad partition arguments")
+    base, extra = divmod(batch, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+class ReplicaNTT:
+    """Many independent short transforms over the GPUs of a node (SURVEY.md 8e "small N:
+    replicas only", BASELINE config #4): the batch is partitioned by ``batch_partition``,
+    every rank transforms its own share with a local batched plan, nothing is exchanged.
+    ``src``/``dst`` are the rank's ``count * n`` elements."""
+
+    def __init__(self, modulus: Modulus, n: int, batch: int, dist=None, rank: int = 0, world: int = 1):
+        from . import NTT
+        if dist is not None:
+            rank, world = dist.get_rank(), dist.get_world_size()
+        self.first, self.count = batch_partition(batch, world, rank)
+        self.n = n
+        self._ntt = NTT(modulus, n, batch=self.count) if self.count else None
+
+    def forward(self, dst, src=None):
+        if self._ntt is not None:
+            self._ntt.compute_forward(dst, src)
+        return dst
+
+    def inverse(self, dst, src=None):
+        if self._ntt is not None:
+            self._ntt.compute_inverse(dst, src)
+        return dst

@@ -356,6 +356,23 @@ def test_distinct_plans_on_concurrent_host_threads(eng, port):
             assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G)), (i, b)
 
 
+def test_replica_mode_shares(eng, port):
+    """ReplicaNTT: rank r of 3 transforms its contiguous share of 10 transforms; together the
+    shares are the batched result (no communication involved, so ranks are emulated in turn)."""
+    from sve_ntt_amd.sharded import ReplicaNTT
+    m, batch, world = 1 << 9, 10, 3
+    src = port.fill_splitmix(m * batch, 5, P)
+    got = np.empty_like(src)
+    for r in range(world):
+        rep = ReplicaNTT(eng.Modulus(P, G), m, batch, rank=r, world=world)
+        lo, hi = rep.first * m, (rep.first + rep.count) * m
+        d = dev(src[lo:hi].copy())
+        rep.forward(d)
+        got[lo:hi] = host(d)
+    for b in range(batch):
+        assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G))
+
+
 def test_plan_lifecycle_returns_device_memory(eng):
     """Creating and destroying plans (device twiddle tables, staging buffer) must not leak."""
     def cycle(count):

@@ -235,3 +235,16 @@ def test_product_never_touches_the_oracle():
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "ntt_oracle" not in text and "libsim" not in text and "cpu_sim/" not in text.replace(
                     "tests/cpu_sim", ""), f
+
+
+def test_batch_partition_covers_the_batch_once():
+    """Replica mode for many small transforms (SURVEY.md 8e "small N"): contiguous shares."""
+    from sve_ntt_amd.sharded import batch_partition
+    for batch in (0, 1, 7, 8, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            shares = [batch_partition(batch, world, r) for r in range(world)]
+            assert shares[0][0] == 0 and sum(c for _, c in shares) == batch
+            assert all(shares[r][0] + shares[r][1] == shares[r + 1][0] for r in range(world - 1))
+            assert max(c for _, c in shares) - min(c for _, c in shares) <= 1
+    with pytest.raises(ValueError):
+        batch_partition(4, 2, 2)
