@@ -6,10 +6,11 @@ caller-level test tests/test_magic_series.py.
     q^(m^2 (m-1)/2) of the Gaussian binomial [m^2 choose m]_q, computed here in exact
     integer arithmetic through the chain [N-k+j choose j]_q, j = 1..k (every member is
     a polynomial, so each division by (1 - q^j) is exact);
-  * qpochhammer[k] = coefficient list of prod_{i=1..k} (1 - q^i).
+  * qpochhammer[k] = coefficient list of prod_{i=1..k} (1 - q^i);
+  * restricted_partitions[k] = p(0, k), p(1, k), ...: the coefficients of its reciprocal.
 
 The reference holds the same numbers as known answers
-(examples/magic-series/test-magic-series.cpp:47-77 and :315-330); when /root/reference
+(examples/magic-series/test-magic-series.cpp:47-77, :104-143 and :315-330); when /root/reference
 is present the script checks that every decimal string it produces occurs there.
 Run:  python tests/golden/make_magic_series.py      (about two minutes for m = 100)
 """
@@ -60,9 +61,24 @@ def qpochhammer(k: int) -> list[int]:
     return c
 
 
+def restricted_partitions(k: int, terms: int) -> list[int]:
+    """p(0, k), ..., p(terms - 1, k): partitions of i into parts <= k = coefficients of
+    1 / prod_{j=1..k} (1 - q^j)."""
+    c = [0] * terms
+    c[0] = 1
+    for j in range(1, min(k, terms - 1) + 1):
+        for t in range(j, terms):
+            c[t] += c[t - j]
+    return c
+
+
+PARTITION_CASES = ((7, 107), (42, 45), (1234, 128))  # (k, number of terms)
+
+
 def main():
     counts = {str(m): str(magic_series_exact(m)) for m in ORDERS}
     poch = {str(k): qpochhammer(k) for k in POCHHAMMER_K}
+    parts = {str(k): restricted_partitions(k, n) for k, n in PARTITION_CASES}
     checked = False
     ref = "/root/reference/examples/magic-series/test-magic-series.cpp"
     if os.path.exists(ref):
@@ -72,6 +88,9 @@ def main():
         flat = re.sub(r"\s+", "", text)
         for k, v in poch.items():
             assert "{" + ",".join(str(x) for x in v) + "}" in flat, f"qpochhammer k={k} disagrees"
+        for k, v in parts.items():
+            # the reference lists at least the first 45 terms for each of these k (:104-143)
+            assert "{" + ",".join(str(x) for x in v[:45]) in flat, f"partitions k={k} disagree"
         checked = True
     out = {
         "source": "tests/golden/make_magic_series.py (exact integer arithmetic)",
@@ -81,6 +100,7 @@ def main():
         "moduli": [{"name": nm, "modulus": f"{p:#x}", "generator": f"{g:#x}"} for nm, p, g in MODULI],
         "counts": counts,
         "qpochhammer": poch,
+        "restricted_partitions": parts,
     }
     with open(os.path.join(HERE, "magic_series.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -43,6 +43,19 @@ def test_magic_series_on_oracle(port, name, p, g):
         assert ms.magic_series_count(be, m, p, NTT_LEN) == int(KAT["counts"][str(m)]) % p, (name, m)
 
 
+@pytest.mark.parametrize("name,p,g", [MODULI[0], MODULI[2], MODULI[7], MODULI[8]],
+                         ids=[MODULI[i][0] for i in (0, 2, 7, 8)])
+def test_reciprocal_gives_restricted_partitions(port, name, p, g):
+    """1 / prod (1 - q^j) by Newton's iteration on transforms == the partition numbers
+    p(i, k) of the reference's RestrictedPartition test (test-magic-series.cpp:96-143)."""
+    be = ms.OracleBackend(port, p, g)
+    for k, want in KAT["restricted_partitions"].items():
+        length = 128 if len(want) > 64 else 64
+        den = ms.one_minus_q_powers(range(1, int(k) + 1), length, p)
+        rec = ms.reciprocal(be, den, length, p)
+        assert [int(x) for x in rec[:len(want)]] == [w % p for w in want[:length]], (name, k)
+
+
 def test_reciprocal_is_a_reciprocal(port):
     p, g = MODULI[-1][1:]
     be = ms.OracleBackend(port, p, g)
@@ -51,6 +64,18 @@ def test_reciprocal_is_a_reciprocal(port):
     full = be.inverse(be.pointwise(be.forward(np.concatenate([den, np.zeros(512, np.uint64)])),
                                    be.forward(np.concatenate([rec, np.zeros(512, np.uint64)]))))
     assert int(full[0]) == 1 and not full[1:512].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,p,g", MODULI, ids=[m[0] for m in MODULI])
+def test_restricted_partitions_on_engine(name, p, g):
+    import sve_ntt_amd as eng
+    be = ms.EngineBackend(eng, p, g)
+    for k, want in KAT["restricted_partitions"].items():
+        length = 128 if len(want) > 64 else 64
+        den = ms.one_minus_q_powers(range(1, int(k) + 1), length, p)
+        rec = ms.reciprocal(be, den, length, p)
+        assert [int(x) for x in rec[:len(want)]] == [w % p for w in want[:length]], (name, k)
 
 
 @pytest.mark.gpu
