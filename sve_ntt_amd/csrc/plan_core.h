@@ -230,13 +230,12 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
   }
   // Widest smallest tile of the column pass is 2^3 columns: the row pass (the
   // block of contiguous elements below the innermost column pass) is >= 2^3.
-  row = rem - MAX_COL_LOGL;
-  const int half = (rem + 1) / 2;
-  if (row < half) row = half;
-  // from 2^22 on the longest row pass wins: 2^22 as 2^9 x 2^13 runs in 66 us against 73 us
-  // for 2^11 x 2^11, 2^23 as 2^10 x 2^13 in 116 against 117 us (r01)
-  if (rem >= 22) row = MAX_ROW_LOGL;
-  if (row > MAX_ROW_LOGL) row = MAX_ROW_LOGL;
+  // The longest row pass wins (fully contiguous 512-byte wave accesses, the column pass keeps
+  // whatever is left): 2^22 as 2^9 x 2^13 runs in 66 us against 73 us for 2^11 x 2^11; batches
+  // of 2^14..2^21-point transforms (2^24 elements in all) are 3-12 % faster than with a balanced
+  // split (tools/split_search.py, r01).  Columns shorter than 2^3 are not worth a 2^13 row.
+  row = (rem - MAX_ROW_LOGL >= 3) ? MAX_ROW_LOGL : MAX_ROW_LOGL - 1;
+  if (row > rem - 1) row = rem - 1;
   rem -= row;
   // (2^25 = 2^12 x 2^13 in two passes beats three: 581 vs 624 us forward, r01)
   const int max_col = tuning().max_col_logl;

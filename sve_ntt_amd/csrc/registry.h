@@ -31,6 +31,17 @@ template <> struct DefaultSteps<11> { using type = Steps<4, 4, 3>; };
 template <> struct DefaultSteps<12> { using type = Steps<4, 4, 4>; };
 template <> struct DefaultSteps<13> { using type = Steps<4, 4, 4, 1>; };
 
+// ROW tiles end on a short step where that helps: a last step of k stages leaves each thread
+// 2^k consecutive elements (8 * 2^k bytes), and a wave's store then touches 64 separate runs;
+// k <= 2 keeps the stores in 16..32-byte lane pieces of one contiguous kilobyte.  Measured on
+// batches (2^24 elements): 2^8 as (4,4) 94 us, see tools/batched_rows.py.
+template <int LOGL> struct RowSteps { using type = typename DefaultSteps<LOGL>::type; };
+template <> struct RowSteps<3> { using type = Steps<2, 1>; };
+template <> struct RowSteps<4> { using type = Steps<3, 1>; };
+template <> struct RowSteps<7> { using type = Steps<4, 2, 1>; };
+template <> struct RowSteps<8> { using type = Steps<4, 3, 1>; };
+template <> struct RowSteps<11> { using type = Steps<4, 4, 2, 1>; };
+
 constexpr int REG_LOGE = 4;
 // ROW tiles are 2^12 elements (256 threads) unless the row itself is longer.
 constexpr int row_logt(int logl) { return logl > 12 ? logl : 12; }
@@ -40,7 +51,7 @@ constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
 
 template <int LOGL, int MODE, bool FLAG>
 using RowTile =
-    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename DefaultSteps<LOGL>::type>;
+    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowSteps<LOGL>::type>;
 template <int LOGL, int MODE>
 using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
                         typename DefaultSteps<LOGL>::type>;
