@@ -356,6 +356,28 @@ def test_distinct_plans_on_concurrent_host_threads(eng, port):
             assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G)), (i, b)
 
 
+def test_sharded_columns_entry_point_equals_chunked_path(eng):
+    """sventt_sharded_columns (the one-call column phase a C/C++ host would use) writes exactly
+    what the Python driver's single-chunk sventt_run_pass_chunk call writes, both directions."""
+    import ctypes
+    from sve_ntt_amd import _lib
+    from sve_ntt_amd.sharded import HipShardEngine
+    n, r_log2, world, rank = 1 << 20, 8, 4, 3
+    e = HipShardEngine(eng.Modulus(P, G), n, r_log2, rank, world)
+    src = torch.randint(0, 1 << 62, (n // world,), dtype=torch.int64, device="cuda")
+    lib = _lib.load()
+    for inverse in (False, True):
+        a = torch.full_like(src, 0x5555555555555555)
+        b = torch.full_like(src, 0x5555555555555555)
+        _lib.check(lib.sventt_sharded_columns(e._cols, int(inverse), a.data_ptr(), src.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+        e.columns_chunk(inverse, b, src, 0, 1)
+        assert torch.equal(a, b), inverse
+    with pytest.raises(eng.SventtError):  # a sharded plan is not a whole transform
+        _lib.check(lib.sventt_forward(e._cols, src.data_ptr(), src.data_ptr(), None))
+    del ctypes
+
+
 def test_replica_mode_shares(eng, port):
     """ReplicaNTT: rank r of 3 transforms its contiguous share of 10 transforms; together the
     shares are the batched result (no communication involved, so ranks are emulated in turn)."""
