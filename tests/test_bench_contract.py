@@ -47,3 +47,12 @@ def test_smoke_entry_point():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_randomised_parity_stress_short():
+    """tools/stress.py for 25 s: random prime / length / split / batch / direction / fused product
+    against the oracle (a 7-minute run is kept in profiles/r01/stress_7min.txt)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress.py"), "25", "7"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
