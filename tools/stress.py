@@ -19,6 +19,7 @@ PRIMES = [(0xFFFFFC6E80000001, 3, 31), (0x3A00000000000001, 3, 57), (0xFFFFFFFF0
           (0x41D33D0D1FBF8001, 6, 15), (0x08AA90297F870001, 3, 16), (0x10001, 3, 16)]
 t_end = time.time() + budget
 cases = fails = 0
+last_report = time.time()
 kinds = {}
 while time.time() < t_end:
     p, g, adic = PRIMES[rng.integers(len(PRIMES))]
@@ -60,6 +61,9 @@ while time.time() < t_end:
             ok = False
             break
     cases += 1
+    if time.time() - last_report > 30:
+        last_report = time.time()
+        print(f"... {cases} cases, {fails} mismatches so far", flush=True)
     key = ntt.describe()
     kinds[key] = kinds.get(key, 0) + 1
     if not ok:

@@ -16,6 +16,7 @@ P, G = 0xFFFFFC6E80000001, 3
 S0 = 0x0123456789ABCDEF
 t_end = time.time() + budget
 cases = fails = 0
+last_report = time.time()
 plans = set()
 while time.time() < t_end:
     log2n = int(rng.integers(20, 29))
@@ -44,6 +45,9 @@ while time.time() < t_end:
     ntt.compute_inverse(dst)
     ok = ok and bool(torch.equal(dst, src))
     cases += 1
+    if time.time() - last_report > 30:
+        last_report = time.time()
+        print(f"... {cases} cases, {fails} mismatches so far", flush=True)
     if not ok:
         fails += 1
         print(f"MISMATCH n=2^{log2n} n0={n0} batch={batch} [{ntt.describe()}]", flush=True)
