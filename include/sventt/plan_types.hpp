@@ -28,7 +28,9 @@
 #include <type_traits>
 
 #include "sventt/modulus.hpp"
+#include "sventt/plan_handle.hpp"
 #include "sventt/transposition.hpp"
+#include "sventt/vector.hpp"
 
 namespace sventt {
 
@@ -139,10 +141,58 @@ class BlockedGenericSVELayer : public detail::six_step_layer<modmul_type, m, inn
 template <class modmul_type, std::uint64_t m, class inner_kernel_type>
 class GenericScalarLayer : public detail::six_step_layer<modmul_type, m, inner_kernel_type> {};
 
+// ---- the kernel concept ------------------------------------------------------------------
+// What NTT<kernel_type> of the reference calls on its kernel (kernel/iterative.hpp:78-106,
+// kernel/recursive.hpp:33-145): prepare_* appends the kernel's auxiliary data to a byte
+// vector, compute_* consumes it through a cursor.  Here the auxiliary data of a whole kernel
+// is one plan record; the plan itself is shared per kernel_type and direction.
+namespace detail {
+
+template <class kernel_type> struct kernel_concept {
+  template <class vector_type> static void prepare_forward(vector_type &aux) {
+    if constexpr (std::is_same_v<vector_type, FakeByteVector>) {
+      aux.push_back(plan_record{});  // sizing only: needs no device
+    } else {
+      aux.push_back(plan_record{shared_plan<kernel_type, SVENTT_FORWARD>()});
+    }
+  }
+
+  template <class vector_type> static void prepare_inverse(vector_type &aux) {
+    if constexpr (std::is_same_v<vector_type, FakeByteVector>) {
+      aux.push_back(plan_record{});
+    } else {
+      aux.push_back(plan_record{shared_plan<kernel_type, SVENTT_INVERSE>()});
+    }
+  }
+
+  static void compute_forward(std::uint64_t *const dst, const std::uint64_t *const src,
+                              const std::byte *&aux) {
+    const plan_record &record{pointer_utility::get_and_advance<plan_record>(aux)};
+    throw_on_error(sventt_forward(record.plan, dst, src, nullptr));
+  }
+
+  static void compute_forward(std::uint64_t *const dst, const std::byte *&aux) {
+    compute_forward(dst, dst, aux);
+  }
+
+  static void compute_inverse(std::uint64_t *const dst, const std::uint64_t *const src,
+                              const std::byte *&aux) {
+    const plan_record &record{pointer_utility::get_and_advance<plan_record>(aux)};
+    throw_on_error(sventt_inverse(record.plan, dst, src, nullptr));
+  }
+
+  static void compute_inverse(std::uint64_t *const dst, const std::byte *&aux) {
+    compute_inverse(dst, dst, aux);
+  }
+};
+
+} // namespace detail
+
 // ---- kernels -------------------------------------------------------------------------
 // IterativeNTT<modulus, m, layers...>: the product of the layer radices must be m
 // (kernel/iterative.hpp:24-27 of the reference).
-template <class modulus_type_, std::uint64_t m, class... layer_types> class IterativeNTT {
+template <class modulus_type_, std::uint64_t m, class... layer_types>
+class IterativeNTT : public detail::kernel_concept<IterativeNTT<modulus_type_, m, layer_types...>> {
 public:
   using modulus_type = modulus_type_;
 
@@ -168,7 +218,9 @@ public:
 // outer layer is a six-step column layer (kernel/recursive.hpp:15-31, :61-75).
 template <class modulus_type_, std::uint64_t m, class layer_type_, class inner_kernel_type_,
           bool separate_twiddle>
-class RecursiveNTT {
+class RecursiveNTT
+    : public detail::kernel_concept<
+          RecursiveNTT<modulus_type_, m, layer_type_, inner_kernel_type_, separate_twiddle>> {
 public:
   using modulus_type = modulus_type_;
   using layer_type = layer_type_;

@@ -5,14 +5,17 @@
 // page-aligned anonymous memory, size()/data()/operator[]/at()/begin()/end(),
 // reset().  On this build it is ordinary host memory; NTT::compute_* accepts it
 // (the engine stages host buffers through the device) as well as device
-// pointers.  The reference's AuxiliaryVector / FakeByteVector carried its
-// SVE-width-dependent twiddle blob and have no counterpart: the device tables are
-// owned by the plan ("not part of the contract").
+// pointers.  AuxiliaryVector / FakeByteVector / pointer_utility keep the interface of
+// the reference's byte blob (vector.hpp:24-48,170-254 there) for code that drives a
+// kernel_type directly (prepare_forward(vec), compute_forward(dst, src, cursor)); on
+// this build the blob holds plan records (plan_handle.hpp), the twiddle tables
+// themselves live on the device and are owned by the plan.
 #ifndef SVENTT_GPU_VECTOR_HPP_INCLUDED
 #define SVENTT_GPU_VECTOR_HPP_INCLUDED
 
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <new>
 #include <stdexcept>
 
@@ -127,6 +130,105 @@ public:
   const value_type *end(void) const { return base + length; }
   const value_type *cbegin(void) const { return base; }
   const value_type *cend(void) const { return base + length; }
+};
+
+// ---- the auxiliary byte blob and its cursor helpers -----------------------------------
+namespace pointer_utility {
+
+// bytes to skip so that an object of type T can sit at offset/address `pos`
+template <class T> std::size_t get_padding(const std::size_t pos) {
+  const std::size_t misalignment{pos % alignof(T)};
+  return misalignment == 0 ? 0 : alignof(T) - misalignment;
+}
+
+template <class T> std::size_t get_padding(const std::byte *const pointer) {
+  return get_padding<T>(reinterpret_cast<std::uintptr_t>(pointer));
+}
+
+template <class T> void skip_padding(const std::byte *&pointer) { pointer += get_padding<T>(pointer); }
+
+// the T at the (aligned) cursor; the cursor moves past it
+template <class T> const T &get_and_advance(const std::byte *&pointer) {
+  skip_padding<T>(pointer);
+  const T *const object{reinterpret_cast<const T *>(pointer)};
+  pointer += sizeof(T);
+  return *object;
+}
+
+template <class T> const T &get(const std::byte *pointer) { return get_and_advance<T>(pointer); }
+
+} // namespace pointer_utility
+
+// Size-only dry run of prepare_*: counts what an AuxiliaryVector would hold.
+class FakeByteVector {
+public:
+  using value_type = std::byte;
+  using size_type = std::uint64_t;
+
+private:
+  size_type bytes{};
+
+public:
+  template <class T> void push_back([[maybe_unused]] const T &value) {
+    bytes += pointer_utility::get_padding<T>(bytes) + sizeof(T);
+  }
+
+  size_type size(void) const { return bytes; }
+
+  template <class T> T &reinterpret_at(const size_type index) {
+    if (index + sizeof(T) > size()) {
+      throw std::out_of_range{"Index out of range"};
+    }
+    static T scratch;
+    return scratch;
+  }
+};
+
+// Fixed-capacity byte vector that prepare_* appends to (std::bad_alloc when full).
+class AuxiliaryVector {
+public:
+  using value_type = std::byte;
+  using size_type = PageMemory<value_type>::size_type;
+
+private:
+  size_type used{};
+  PageMemory<value_type> storage;
+
+public:
+  AuxiliaryVector(void) = default;
+
+  AuxiliaryVector(const size_type capacity, const bool allocate_huge_pages = false)
+      : storage{capacity, allocate_huge_pages} {}
+
+  size_type size(void) const { return used; }
+  size_type capacity(void) const { return storage.size(); }
+  value_type *data(void) { return storage.data(); }
+  const value_type *data(void) const { return storage.data(); }
+  value_type &operator[](const size_type index) { return storage[index]; }
+  const value_type &operator[](const size_type index) const { return storage[index]; }
+
+  value_type &at(const size_type index) {
+    if (index >= size()) {
+      throw std::out_of_range{"Index out of range"};
+    }
+    return storage[index];
+  }
+
+  template <class T> T &reinterpret_at(const size_type index) {
+    if (index + sizeof(T) > size()) {
+      throw std::out_of_range{"Index out of range"};
+    }
+    return *reinterpret_cast<T *>(&storage[index]);
+  }
+
+  template <class T> void push_back(const T &value) {
+    const size_type at{used + pointer_utility::get_padding<T>(used)};
+    if (at + sizeof(T) > capacity()) {
+      throw std::bad_alloc{};
+    }
+    std::memcpy(&storage[at], &value, sizeof(T));
+    used = at + sizeof(T);
+  }
 };
 
 } // namespace sventt

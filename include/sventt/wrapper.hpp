@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "sventt/plan_handle.hpp"
 #include "sventt/status.hpp"
 #include "sventt_hip.h"
 
@@ -32,23 +33,6 @@ public:
 private:
   sventt_plan *plan{};
 
-  // The R of an explicit six-step split, if it is one the engine's column pass
-  // can take (at most 2^11 rows, at least 8 columns); otherwise let it choose.
-  static constexpr std::uint32_t preferred_rows_log2(void) {
-    constexpr std::uint64_t rows{kernel_type::get_six_step_rows()};
-    constexpr std::uint64_t m{kernel_type::get_m()};
-    if (rows < 2 || rows >= m) {
-      return 0;
-    }
-    const std::uint32_t log2_rows{static_cast<std::uint32_t>(std::countr_zero(rows))};
-    const std::uint32_t log2_cols{static_cast<std::uint32_t>(std::countr_zero(m / rows))};
-    const std::uint32_t wide{log2_rows >= 9 ? 3u : 12u - log2_rows};
-    if (log2_rows > 11 || log2_cols > 13 || (log2_cols < wide && (log2_cols < 3 || log2_rows > 8))) {
-      return 0;
-    }
-    return log2_rows;
-  }
-
 public:
   NTT(const bool enable_forward = true, const bool enable_inverse = true,
       [[maybe_unused]] const bool allocate_huge_pages = true) {
@@ -57,9 +41,7 @@ public:
     if (flags == 0) {
       return;  // the reference allows an NTT with neither table; it then cannot transform
     }
-    detail::throw_on_error(sventt_plan_create(modulus_type::get_modulus(),
-                                              modulus_type::get_generator(), kernel_type::get_m(),
-                                              preferred_rows_log2(), 1, flags, &plan));
+    plan = detail::create_plan<kernel_type>(flags);
   }
 
   NTT(const NTT &) = delete;

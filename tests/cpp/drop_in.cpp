@@ -215,6 +215,44 @@ static bool check_transposition(void) {
   return ok;
 }
 
+// Driving a kernel_type directly, the way NTT<> of the reference does (wrapper.hpp:13-47,
+// 50-82): size the auxiliary blob with a FakeByteVector, fill an AuxiliaryVector, run with a
+// cursor that must end exactly at the end of what prepare_* wrote.
+static bool check_kernel_concept(void) {
+  using kernel_type = test62::recursive_radix248;
+  using modulus_type = kernel_type::modulus_type;
+  constexpr std::uint64_t N{modulus_type::get_modulus()}, g{modulus_type::get_generator()};
+  constexpr std::uint64_t m{kernel_type::get_m()};
+  FakeByteVector sizing;
+  kernel_type::prepare_forward(sizing);
+  const std::uint64_t forward_bytes{sizing.size()};
+  kernel_type::prepare_inverse(sizing);
+  AuxiliaryVector aux{sizing.size(), false};
+  kernel_type::prepare_forward(aux);
+  bool ok{aux.size() == forward_bytes};
+  kernel_type::prepare_inverse(aux);
+  ok &= aux.size() == sizing.size() && aux.size() > 0;
+
+  std::vector<std::uint64_t> src(m), dst(m, UINT64_C(0x5555555555555555)), ref(m);
+  oracle_fill_iota(src.data(), m, 12345);
+  oracle_ntt_forward(ref.data(), src.data(), m, N, g);
+  const std::byte *cursor{aux.data()};
+  kernel_type::compute_forward(dst.data(), src.data(), cursor);
+  ok &= cursor == aux.data() + forward_bytes && dst == ref;
+  kernel_type::compute_inverse(dst.data(), cursor);  // the in-place overload, inverse record
+  ok &= cursor == aux.data() + aux.size() && dst == src;
+
+  AuxiliaryVector too_small{forward_bytes - 1, false};
+  try {
+    kernel_type::prepare_forward(too_small);
+    ok = false;
+  } catch (const std::bad_alloc &) {  // vector.hpp:245-247 of the reference
+  }
+  std::printf(ok ? "ok kernel concept (prepare / compute with an auxiliary cursor)\n"
+                 : "MISMATCH kernel concept\n");
+  return ok;
+}
+
 // compile-time facts the reference's API promises
 static_assert(readme_blocked_six_step::kernel_type::get_m() == (std::uint64_t{1} << 17));
 static_assert(NTT<readme_blocked_six_step::kernel_type>::get_m() == (std::uint64_t{1} << 17));
@@ -247,6 +285,7 @@ int main(int argc, char **argv) {
   ok &= check<big::kernel_type, false>("six-step 2^24 = 2^11 x 2^13");
   ok &= check_errors();
   ok &= check_transposition();
+  ok &= check_kernel_concept();
   std::printf(ok ? "ALL OK\n" : "FAILED\n");
   return ok ? 0 : 1;
 }
