@@ -60,7 +60,7 @@ def main() -> None:
     got = dst.cpu().numpy().view(np.uint64)
     mine = want[rank * (n // world):(rank + 1) * (n // world)]   # rows [rank*Rl, (rank+1)*Rl)
     ok_f = bool(np.array_equal(got, mine))
-    assert src.cpu().numpy().view(np.uint64).tolist() == slab.tolist() or True
+    assert np.array_equal(src.cpu().numpy().view(np.uint64), slab), "forward modified its source"
 
     back = torch.full_like(src, 0x5555555555555555)
     sh.inverse(back, dst)

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Column pass of a single-GPU 2^24 plan against the sharded plans' (one launch, and cut into
+four pipeline chunks): same tile shape, same stride."""
 import os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import sve_ntt_amd as eng
 from sve_ntt_amd.sharded import HipShardEngine

@@ -2,7 +2,6 @@
 """LDS bank-conflict degree of every LDS exchange of a tile shape under a swizzle.
 For each step that touches LDS: the ds_*_b64 of element v of set g by the 32 lanes of a
 half-wave; degree = max lanes on one of the 32 8-byte bank pairs (1 = conflict free)."""
-import sys
 
 def phys_default(I):
     return I ^ ((I >> 4) & 31)
