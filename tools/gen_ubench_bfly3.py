@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Generates tools/ubench_bfly3.hip: the radix-16 register step of ubench_bfly2 with W butterflies
+interleaved per asm statement (W = 1, 2, 4), to find how much instruction-level parallelism the
+EXEC-masked assembly needs at 4 waves per SIMD.  Not part of the product.
+
+    python tools/gen_ubench_bfly3.py > tools/ubench_bfly3.hip
+"""
+import sys
+
+DATA_BASE = 0          # x_i = v[2i : 2i+1]
+TEMP_BASE = 32
+TEMP_PER_SLOT = 12
+SG_BASE = 60           # carries: slot s uses s[SG_BASE+4s : +1] (borrow) and s[+2 : +3] (carry)
+
+
+class Slot:
+    def __init__(self, s, xa, xb, w0, w1):
+        t = TEMP_BASE + TEMP_PER_SLOT * s
+        self.m0, self.m1, self.m2, self.h, self.z, self.d = (t, t + 2, t + 4, t + 6, t + 8, t + 10)
+        self.e = self.m2
+        self.sb = 's[%d:%d]' % (SG_BASE + 4 * s, SG_BASE + 4 * s + 1)
+        self.sc = 's[%d:%d]' % (SG_BASE + 4 * s + 2, SG_BASE + 4 * s + 3)
+        self.xl, self.xh = DATA_BASE + 2 * xa, DATA_BASE + 2 * xa + 1
+        self.yl, self.yh = DATA_BASE + 2 * xb, DATA_BASE + 2 * xb + 1
+        self.w0, self.w1 = w0, w1
+
+
+def pair(r):
+    return 'v[%d:%d]' % (r, r + 1)
+
+
+def mont_core(S, dl, dh):
+    """thi -> S.h, g -> S.m2 ; plain list of single instructions (all full-EXEC VALU)."""
+    m0, m1, m2, h, z = S.m0, S.m1, S.m2, S.h, S.z
+    return [
+        'v_mad_u64_u32 %s, vcc, v%d, %s, 0' % (pair(m0), dl, S.w0),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_mad_u64_u32 %s, vcc, v%d, %s, %s' % (pair(m1), dl, S.w1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m1 + 1),
+        'v_mad_u64_u32 %s, vcc, v%d, %s, %s' % (pair(h), dh, S.w1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m1),
+        'v_mad_u64_u32 %s, vcc, v%d, %s, %s' % (pair(m2), dh, S.w0, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m2 + 1),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[ni0], 0' % (pair(m1), m0),
+        'v_mul_lo_u32 v%d, v%d, %%[ni1]' % (m0 + 1, m0),
+        'v_mul_lo_u32 v%d, v%d, %%[ni0]' % (m2, m2),
+        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),
+        'v_add3_u32 v%d, v%d, v%d, v%d' % (m1 + 1, m1 + 1, m0 + 1, m2),
+        'v_mul_hi_u32 v%d, v%d, %%[n0]' % (z, m1),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[n1], %s' % (pair(m0), m1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[n1], %s' % (pair(m2), m1 + 1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m0),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[n0], %s' % (pair(m0), m1 + 1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(m2), pair(m2), pair(z)),
+    ]
+
+
+import os
+FIXMODE = os.environ.get('FIXMODE', 'exec')
+def fix(mask_expr, reg):
+    if FIXMODE == 'none':
+        return []
+    if FIXMODE == 'uncond':
+        return ['v_lshl_add_u64 %s, %s, 0, %%[N]' % (pair(reg), pair(reg))]
+    return [mask_expr, 'v_lshl_add_u64 %s, %s, 0, %%[N]' % (pair(reg), pair(reg))]
+
+
+def bfly_fwd(S):
+    """list of items; an item is a str (one instruction) or a tuple ('fix', [instrs]) that must
+    run with EXEC narrowed and is followed by a restore."""
+    x, y = S.xl, S.yl
+    items = [
+        'v_mov_b32 v%d, 0' % (S.z + 1),
+        'v_sub_co_u32 v%d, %s, v%d, v%d' % (S.d, S.sb, S.xl, S.yl),
+        'v_lshl_add_u64 %s, %s, 0, %%[negN]' % (pair(S.e), pair(y)),
+        'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (S.d + 1, S.sb, S.xh, S.yh, S.sb),
+        'v_add_co_u32 v%d, %s, v%d, v%d' % (S.xl, S.sc, S.xl, S.e),
+        ('fix', fix('s_mov_b64 exec, %s' % S.sb, S.d)),
+        'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (S.xh, S.sc, S.xh, S.e + 1, S.sc),
+        'NOPGAP',
+        ('fix', fix('s_andn2_b64 exec, %%[save], %s' % S.sc, x)),
+    ]
+    items += mont_core(S, S.d, S.d + 1)
+    items += [
+        'v_sub_co_u32 v%d, %s, v%d, v%d' % (S.yl, S.sb, S.h, S.m2),
+        'NOPGAP',
+        'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (S.yh, S.sb, S.h + 1, S.m2 + 1, S.sb),
+        'NOPGAP',
+        ('fix', fix('s_mov_b64 exec, %s' % S.sb, y)),
+    ]
+    return items
+
+
+def interleave(streams):
+    """round-robin merge; consecutive fix groups share one EXEC restore."""
+    out = []
+    idx = [0] * len(streams)
+    in_fix = False
+    W = len(streams)
+    while any(i < len(s) for i, s in zip(idx, streams)):
+        for k, s in enumerate(streams):
+            if idx[k] >= len(s):
+                continue
+            it = s[idx[k]]
+            idx[k] += 1
+            if it == 'NOPGAP':
+                if W == 1:
+                    if in_fix:
+                        out.append('s_mov_b64 exec, %[save]')
+                        in_fix = False
+                    out.append('s_nop 0')
+                continue
+            if isinstance(it, tuple):
+                out.extend(it[1])
+                in_fix = True
+            else:
+                if in_fix:
+                    out.append('s_mov_b64 exec, %[save]')
+                    in_fix = False
+                out.append(it)
+    if in_fix:
+        out.append('s_mov_b64 exec, %[save]')
+    return out
+
+
+def asm_stmt(pairs, wnames, W):
+    """one asm statement for W butterflies; pairs = [(a, b)], wnames = C expressions"""
+    slots = []
+    ops_in = []
+    for s, ((a, b), wn) in enumerate(zip(pairs, wnames)):
+        slots.append(Slot(s, a, b, '%%[w%d0]' % s, '%%[w%d1]' % s))
+        ops_in.append('[w%d0] "v"((u32)(%s))' % (s, wn))
+        ops_in.append('[w%d1] "v"((u32)((%s) >> 32))' % (s, wn))
+    body = interleave([bfly_fwd(S) for S in slots])
+    text = ''.join('      "%s\\n\\t"\n' % l for l in body)
+    outs = []
+    for (a, b) in pairs:
+        outs.append('"+{v[%d:%d]}"(x%d)' % (2 * a, 2 * a + 1, a))
+        outs.append('"+{v[%d:%d]}"(x%d)' % (2 * b, 2 * b + 1, b))
+    consts = ['[N] "s"(f.N)', '[negN] "s"(f.negN)', '[n0] "s"((u32)f.N)', '[n1] "s"((u32)(f.N >> 32))',
+              '[ni0] "s"((u32)f.Ninv)', '[ni1] "s"((u32)(f.Ninv >> 32))', '[save] "s"(save)']
+    clob = ['"vcc"', '"scc"']
+    clob += ['"v%d"' % r for r in range(TEMP_BASE, TEMP_BASE + TEMP_PER_SLOT * W)]
+    clob += ['"s%d"' % r for r in range(SG_BASE, SG_BASE + 4 * W)]
+    return ('    asm volatile(\n%s      : %s\n      : %s\n      : %s);\n'
+            % (text, ', '.join(outs), ', '.join(ops_in + consts), ', '.join(clob)))
+
+
+def kernel(W):
+    lines = ['__global__ __launch_bounds__(512) void k_asm_w%d(u64 *out, Field f, u64 seed) {' % W,
+             '  u64 x[16], w[8];', '  init(x, w, f, seed);']
+    lines.append('  u64 ' + ', '.join('x%d = x[%d]' % (i, i) for i in range(16)) + ';')
+    lines.append('  const u64 save = __builtin_amdgcn_read_exec();')
+    lines.append('  for (int it = 0; it < ITER; ++it) {')
+    for r in (3, 2, 1, 0):
+        bf = [(v, v + (1 << r)) for v in range(16) if not v & (1 << r)]
+        for g in range(0, 8, W):
+            lines.append(asm_stmt(bf[g:g + W], ['w[%d]' % (g + k) for k in range(W)], W))
+    lines.append('  }')
+    lines.append('  u64 *o = out + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;')
+    lines.append('  ' + ' '.join('o[%d] = x%d;' % (i, i) for i in range(16)))
+    lines.append('}')
+    return '\n'.join(lines)
+
+
+def main():
+    src = open(__file__.replace('gen_ubench_bfly3.py', 'ubench_bfly2.hip')).read()
+    head = src.split('// ---- variant 1')[0]
+    tail = src[src.index('template <class K> static int timeit'):src.index('int main()')]
+    print('// GENERATED by tools/gen_ubench_bfly3.py -- do not edit.  W-way interleaved assembly butterflies.')
+    print(head)
+    for W in (1, 2, 4):
+        print(kernel(W))
+        print()
+    print(tail)
+    print('''int main() {
+  u64 *d; CHECK(hipMalloc(&d, (size_t)256 * 4 * 512 * 16 * 8));
+  std::vector<u64> ref, got;
+  for (int pass = 0; pass < 2; ++pass) {
+    const size_t lds = pass == 0 ? 64 * 1024 : 0;
+    const int bpc = pass == 0 ? 2 : 4;
+    if (timeit("hipcc C++ (cndmask)", k_cxx, d, bpc, lds, &ref)) return 1;
+#define RUN(K) if (timeit(#K, K, d, bpc, lds, &got)) return 1; { size_t bad = 0; for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != got[i]; printf("   vs C++: %zu mismatches of %zu\\n", bad, ref.size()); }
+    RUN(k_asm_w1) RUN(k_asm_w2) RUN(k_asm_w4)
+  }
+  return 0;
+}''')
+
+
+if __name__ == '__main__':
+    main()
