@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""Generates stage_asm.inc: the butterfly stages of an E = 16 tile step as gfx950 assembly.
+
+    python sve_ntt_amd/csrc/gen_stage_asm.py > sve_ntt_amd/csrc/stage_asm.inc
+
+Why assembly.  Both 2^24 kernels are bound by VALU issue.  hipcc turns every
+conditional "+N" of the canonical 64-bit-modulus arithmetic (reference: modmul/sve/p-adic-64.hpp:
+44-62, 90-92: compare-and-add) into two v_cndmask_b32 and a 64-bit add.  Here the borrow / carry
+SGPR pair that v_subb_co / v_addc_co produce is moved straight into EXEC and the correction is ONE
+v_lshl_add_u64 on the lanes that need it: 24 instead of 30 full-rate-class VALU instructions per
+butterfly (profiles/r02/ubench_bfly_asm.txt: 135 against 155 cycles at 4 waves per SIMD).  That
+needs the 32-bit halves of 64-bit values by name, which inline-asm operands cannot give, so the 16
+tile elements of a thread live in FIXED registers (x_i = v[2i:2i+1], bound with "{v[a:b]}"
+constraints) and the temporaries are fixed too.  Four butterflies are interleaved per asm statement
+so that every dependent instruction has three independent ones in front of it.
+
+Arithmetic is exactly csrc/field64.h's (montmul / addmod / submod / butterfly_fwd / butterfly_inv):
+same values in, same canonical values out; tests compare the kernels with the oracle bit for bit.
+
+Register map (per thread): data v0..v31; slot s of an asm statement uses v[32+12s .. 43+12s] and
+s[60+4s .. 63+4s]; vcc is the unused carry-out of v_mad_u64_u32.  All of them are declared clobbered.
+"""
+import sys
+
+E = 16
+TEMP_BASE = 32
+TEMP_PER_SLOT = 12
+SG_BASE = 60
+MAXW = 4
+
+
+def pair(r):
+    return 'v[%d:%d]' % (r, r + 1)
+
+
+class Slot:
+    def __init__(self, s):
+        t = TEMP_BASE + TEMP_PER_SLOT * s
+        self.m0, self.m1, self.m2, self.h, self.z, self.d = (t, t + 2, t + 4, t + 6, t + 8, t + 10)
+        self.sb = 's[%d:%d]' % (SG_BASE + 4 * s, SG_BASE + 4 * s + 1)
+        self.sc = 's[%d:%d]' % (SG_BASE + 4 * s + 2, SG_BASE + 4 * s + 3)
+
+
+def zero_ext_init(S):
+    return ['v_mov_b32 v%d, 0' % (S.z + 1)]
+
+
+def mont(S, al, ah, w0, w1):
+    """h <- hi64(a*w), m2 <- hi64(q*N) with q = lo64(a*w) * N^-1 mod 2^64 (field64.h: montmul).
+    al/ah: the multiplicand's halves (VGPR operand texts); w0/w1: the multiplier's (VGPR or SGPR)."""
+    m0, m1, m2, h, z = S.m0, S.m1, S.m2, S.h, S.z
+    return [
+        'v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(m0), al, w0),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m1), al, w1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m1 + 1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(h), ah, w1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, w0, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m2 + 1),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[ni0], 0' % (pair(m1), m0),
+        'v_mul_lo_u32 v%d, v%d, %%[ni1]' % (m0 + 1, m0),
+        'v_mul_lo_u32 v%d, v%d, %%[ni0]' % (m2, m2),
+        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),
+        'v_add3_u32 v%d, v%d, v%d, v%d' % (m1 + 1, m1 + 1, m0 + 1, m2),
+        'v_mul_hi_u32 v%d, v%d, %%[n0]' % (z, m1),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[n1], %s' % (pair(m0), m1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[n1], %s' % (pair(m2), m1 + 1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m0),
+        'v_mad_u64_u32 %s, vcc, v%d, %%[n0], %s' % (pair(m0), m1 + 1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(m2), pair(m2), pair(z)),
+    ]
+
+
+def fix_if(S_mask, reg):
+    """+N on the lanes whose bit is set in the SGPR pair"""
+    return ('fix', 's_and_b64 exec, %%[save], %s' % S_mask, 'v_lshl_add_u64 %s, %s, 0, %%[N]' % (pair(reg), pair(reg)))
+
+
+def fix_ifnot(S_mask, reg):
+    return ('fix', 's_andn2_b64 exec, %%[save], %s' % S_mask, 'v_lshl_add_u64 %s, %s, 0, %%[N]' % (pair(reg), pair(reg)))
+
+
+def sub_into(S, dl, al, ah, bl, bh):
+    """v[dl:dl+1] = a - b, borrow in S.sb"""
+    return ['v_sub_co_u32 v%d, %s, v%d, v%d' % (dl, S.sb, al, bl),
+            'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (dl + 1, S.sb, ah, bh, S.sb)]
+
+
+def mont_result(S, dl):
+    """v[dl:dl+1] = h - m2 (+N on borrow): the canonical Montgomery product"""
+    return sub_into(S, dl, S.h, S.h + 1, S.m2, S.m2 + 1) + [fix_if(S.sb, dl)]
+
+
+def bf_fwd(S, x, y, w0, w1):
+    """(x, y) <- (x + y, (x - y) * w)      field64.h: butterfly_fwd"""
+    e = S.m2
+    return (zero_ext_init(S) +
+            ['v_sub_co_u32 v%d, %s, v%d, v%d' % (S.d, S.sb, x, y),
+             'v_lshl_add_u64 %s, %s, 0, %%[negN]' % (pair(e), pair(y)),
+             'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (S.d + 1, S.sb, x + 1, y + 1, S.sb),
+             'v_add_co_u32 v%d, %s, v%d, v%d' % (x, S.sc, x, e),
+             fix_if(S.sb, S.d),
+             'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (x + 1, S.sc, x + 1, e + 1, S.sc),
+             fix_ifnot(S.sc, x)] +
+            mont(S, 'v%d' % S.d, 'v%d' % (S.d + 1), w0, w1) + mont_result(S, y))
+
+
+def bf_plain(S, x, y):
+    """(x, y) <- (x + y, x - y)            field64.h: twiddle-less butterfly"""
+    e = S.m2
+    return ['v_lshl_add_u64 %s, %s, 0, %%[negN]' % (pair(e), pair(y)),
+            'v_sub_co_u32 v%d, %s, v%d, v%d' % (y, S.sb, x, y),
+            'v_add_co_u32 v%d, %s, v%d, v%d' % (x, S.sc, x, e),
+            'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (y + 1, S.sb, x + 1, y + 1, S.sb),
+            'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (x + 1, S.sc, x + 1, e + 1, S.sc),
+            fix_if(S.sb, y),
+            fix_ifnot(S.sc, x)]
+
+
+def bf_inv(S, x, y, w0, w1):
+    """(x, y) <- (x + y*w, x - y*w)        field64.h: butterfly_inv"""
+    e = S.m0
+    return (zero_ext_init(S) + mont(S, 'v%d' % y, 'v%d' % (y + 1), w0, w1) + mont_result(S, S.d) +
+            ['v_lshl_add_u64 %s, %s, 0, %%[negN]' % (pair(e), pair(S.d)),
+             'v_sub_co_u32 v%d, %s, v%d, v%d' % (y, S.sb, x, S.d),
+             'v_add_co_u32 v%d, %s, v%d, v%d' % (x, S.sc, x, e),
+             'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (y + 1, S.sb, x + 1, S.d + 1, S.sb),
+             'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (x + 1, S.sc, x + 1, e + 1, S.sc),
+             fix_if(S.sb, y),
+             fix_ifnot(S.sc, x)])
+
+
+def mul_inplace(S, x, w0, w1):
+    """x <- x * w"""
+    return zero_ext_init(S) + mont(S, 'v%d' % x, 'v%d' % (x + 1), w0, w1) + mont_result(S, x)
+
+
+def mul_composed(S, x, hi0, hi1, lo0, lo1):
+    """x <- x * (hi * lo)                  tile_ntt.h: twist_lookup + montmul"""
+    return (zero_ext_init(S) + mont(S, hi0, hi1, lo0, lo1) + mont_result(S, S.d) +
+            mont(S, 'v%d' % x, 'v%d' % (x + 1), 'v%d' % S.d, 'v%d' % (S.d + 1)) + mont_result(S, x))
+
+
+# ---- scheduling -------------------------------------------------------------------------------
+def interleave(streams):
+    """Round-robin merge of the slots' instruction streams.  Corrections run with EXEC narrowed;
+    neighbouring ones share the restore."""
+    out = []
+    idx = [0] * len(streams)
+    while any(i < len(s) for i, s in zip(idx, streams)):
+        for k, s in enumerate(streams):
+            if idx[k] < len(s):
+                out.append(s[idx[k]])
+                idx[k] += 1
+    flat = []
+    narrowed = False
+    for it in out:
+        if isinstance(it, tuple):
+            flat += [it[1], it[2]]
+            narrowed = True
+        else:
+            if narrowed:
+                flat.append('s_mov_b64 exec, %[save]')
+                narrowed = False
+            flat.append(it)
+    if narrowed:
+        flat.append('s_mov_b64 exec, %[save]')
+    return hazards(flat)
+
+
+def sgpr_written(ins):
+    op = ins.split()[0]
+    if op in ('v_sub_co_u32', 'v_subb_co_u32', 'v_add_co_u32', 'v_addc_co_u32'):
+        return ins.split(',')[1].strip()
+    return None
+
+
+def sgpr_read(ins):
+    op = ins.split()[0]
+    if op in ('v_subb_co_u32', 'v_addc_co_u32'):
+        return ins.split(',')[-1].strip()
+    if op in ('s_and_b64', 's_andn2_b64'):
+        return ins.split(',')[-1].strip()
+    return None
+
+
+def hazards(seq):
+    """gfx950: two wait states between a VALU write of an SGPR pair and a VALU read of it as carry-in
+    (hipcc's own code: v_sub_co / s_nop 1 / v_subb_co); the same distance is kept before SALU reads."""
+    out = []
+    for ins in seq:
+        r = sgpr_read(ins)
+        if r is not None:
+            for back in (1, 2):  # two other instructions between the write and the read
+                if len(out) >= back and sgpr_written(out[-back]) == r:
+                    out.append('s_nop %d' % (2 - back))
+                    break
+        out.append(ins)
+    return out
+
+
+# ---- C++ wrappers -------------------------------------------------------------------------------
+CONSTS = ['[N] "s"(c.N)', '[negN] "s"(c.negN)', '[n0] "s"(c.n0)', '[n1] "s"(c.n1)', '[ni0] "s"(c.ni0)',
+          '[ni1] "s"(c.ni1)', '[save] "s"(c.save)']
+
+
+def clobbers(W):
+    cl = ['"vcc"', '"scc"']
+    cl += ['"v%d"' % r for r in range(TEMP_BASE, TEMP_BASE + TEMP_PER_SLOT * W)]
+    cl += ['"s%d"' % r for r in range(SG_BASE, SG_BASE + 4 * W)]
+    return ', '.join(cl)
+
+
+def asm_stmt(streams, data_regs, inputs):
+    body = interleave(streams)
+    text = ''.join('        "%s\\n\\t"\n' % l for l in body)
+    outs = ', '.join('"+{v[%d:%d]}"(x[%d])' % (2 * i, 2 * i + 1, i) for i in data_regs)
+    return ('    asm volatile(\n%s        : %s\n        : %s\n        : %s);\n'
+            % (text, outs, ', '.join(inputs + CONSTS), clobbers(len(streams))))
+
+
+def halves(name, k):
+    return ['[%s%d0] "v"((u32)(%s%d))' % (name, k, name, k), '[%s%d1] "v"((u32)(%s%d >> 32))' % (name, k, name, k)]
+
+
+def butterflies(r):
+    return [(i, i + (1 << r)) for i in range(E) if not i & (1 << r)]
+
+
+def trivial(i, r):
+    return (i & ((1 << r) - 1)) == 0
+
+
+def gen_bfly_group(mode, r, grp, triv):
+    bfs = butterflies(r)[4 * grp:4 * grp + 4]
+    streams, inputs, regs = [], [], []
+    for k, (a, b) in enumerate(bfs):
+        S = Slot(k)
+        regs += [a, b]
+        if triv and trivial(a, r):
+            streams.append(bf_plain(S, 2 * a, 2 * b))
+        else:
+            inputs += halves('w', k)
+            fn = bf_fwd if mode == 'MODE_FWD' else bf_inv
+            streams.append(fn(S, 2 * a, 2 * b, '%%[w%d0]' % k, '%%[w%d1]' % k))
+    s = 'template <> struct BflyGroup<%s, %d, %d, %s> {\n' % (mode, r, grp, 'true' if triv else 'false')
+    s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 w0, u64 w1, u64 w2, u64 w3,\n'
+          '                                             const AsmConsts &c) {\n')
+    s += asm_stmt(streams, sorted(regs), inputs)
+    s += '  }\n};\n'
+    return s
+
+
+def gen_mont_group(grp):
+    streams, inputs = [], []
+    for k in range(4):
+        streams.append(mul_inplace(Slot(k), 2 * (4 * grp + k), '%%[w%d0]' % k, '%%[w%d1]' % k))
+        inputs += halves('w', k)
+    s = 'template <> struct MontGroup<%d> {\n' % grp
+    s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 w0, u64 w1, u64 w2, u64 w3,\n'
+          '                                             const AsmConsts &c) {\n')
+    s += asm_stmt(streams, range(4 * grp, 4 * grp + 4), inputs)
+    s += '  }\n};\n'
+    return s
+
+
+def gen_twist_group(grp):
+    streams, inputs = [], []
+    for k in range(4):
+        streams.append(mul_composed(Slot(k), 2 * (4 * grp + k), '%%[hi%d0]' % k, '%%[hi%d1]' % k,
+                                    '%%[lo%d0]' % k, '%%[lo%d1]' % k))
+        inputs += halves('hi', k) + halves('lo', k)
+    s = 'template <> struct TwistGroup<%d> {\n' % grp
+    s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 hi0, u64 hi1, u64 hi2, u64 hi3,\n'
+          '                                             u64 lo0, u64 lo1, u64 lo2, u64 lo3,\n'
+          '                                             const AsmConsts &c) {\n')
+    s += asm_stmt(streams, range(4 * grp, 4 * grp + 4), inputs)
+    s += '  }\n};\n'
+    return s
+
+
+def gen_scale_group(r, grp):
+    """x0 of every butterfly of BflyGroup<., r, grp, .> times a wave-uniform factor"""
+    bfs = butterflies(r)[4 * grp:4 * grp + 4]
+    streams = [mul_inplace(Slot(k), 2 * a, '%[s0]', '%[s1]') for k, (a, _) in enumerate(bfs)]
+    s = 'template <> struct ScaleGroup<%d, %d> {\n' % (r, grp)
+    s += '  static __device__ __forceinline__ void run(u64 (&x)[16], u64 s, const AsmConsts &c) {\n'
+    s += asm_stmt(streams, [a for a, _ in bfs], ['[s0] "s"((u32)s)', '[s1] "s"((u32)(s >> 32))'])
+    s += '  }\n};\n'
+    return s
+
+
+HEADER = '''// GENERATED by gen_stage_asm.py -- do not edit; regenerate with
+//     python sve_ntt_amd/csrc/gen_stage_asm.py > sve_ntt_amd/csrc/stage_asm.inc
+// The butterfly stages of an E = 16 tile step as gfx950 assembly on fixed registers (x_i =
+// v[2i:2i+1]); see the generator's docstring for the why and the register map.  Included by
+// tile_ntt.h inside namespace sventt_hip, device compilation only.
+
+struct AsmConsts {
+  u64 N, negN;
+  u32 n0, n1, ni0, ni1;
+  u64 save;  // EXEC at kernel entry (all lanes of a live workgroup)
+};
+
+// four butterflies (x_a, x_a + 2^R) of stage bit R: the GRP-th four in ascending a.
+// TRIV: the stage's twiddles with (a mod 2^R) == 0 are omega^0 (lowest step of a transform).
+template <int MODE, int R, int GRP, bool TRIV> struct BflyGroup;
+// x[4 GRP + k] *= w_k
+template <int GRP> struct MontGroup;
+// x[4 GRP + k] *= hi_k * lo_k
+template <int GRP> struct TwistGroup;
+// the first elements of BflyGroup<., R, GRP, .>'s butterflies times s
+template <int R, int GRP> struct ScaleGroup;
+'''
+
+
+def main():
+    out = [HEADER]
+    for mode in ('MODE_FWD', 'MODE_INV'):
+        for r in range(4):
+            for grp in range(2):
+                for triv in (False, True):
+                    out.append(gen_bfly_group(mode, r, grp, triv))
+    for grp in range(4):
+        out.append(gen_mont_group(grp))
+        out.append(gen_twist_group(grp))
+    for r in range(4):
+        for grp in range(2):
+            out.append(gen_scale_group(r, grp))
+    sys.stdout.write('\n'.join(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -38,6 +38,15 @@ namespace sventt_hip {
 
 enum : int { MODE_FWD = 0, MODE_INV = 1 };
 
+// Device builds run the butterfly stages of E = 16 tiles as generated gfx950 assembly
+// (gen_stage_asm.py: same arithmetic as field64.h, conditional +N under an EXEC mask).
+// -DSVENTT_NO_STAGE_ASM keeps hipcc's code for A/B measurements; the host replay
+// (tests/cpu_sim) always runs the C++ below.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SVENTT_NO_STAGE_ASM)
+#define SVENTT_STAGE_ASM 1
+#include "stage_asm.inc"
+#endif
+
 // Arguments of one pass (passed by value to the kernel: lives in SGPRs).
 struct PassArgs {
   u64 *dst;
@@ -191,9 +200,163 @@ struct TileNTT {
     return montmul(hi, lo, a.f);
   }
 
+#if defined(SVENTT_STAGE_ASM)
+  // first element of the b-th butterfly (ascending) of stage bit r over 16 registers
+  static constexpr int bf_first(int r, int b) { return ((b >> r) << (r + 1)) | (b & ((1 << r) - 1)); }
+
+  // The same step with all G sets of the thread held at once (x[g*R + v]) and the stages run
+  // by the assembly groups of stage_asm.inc, four butterflies per statement.
+  template <int SI>
+  __device__ __forceinline__ static void step_asm(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
+    constexpr int k = STEPS::k[SI];
+    constexpr int HI = LOGL - STEPS::sum(SI);
+    constexpr int LO = HI - k;
+    constexpr int lo = F0 + LO, hi = F0 + HI;
+    constexpr int R = 1 << k;
+    constexpr int G = E >> k;
+    static_assert(E == 16, "assembly stages are generated for 16 elements per thread");
+    constexpr bool from_hbm = (MODE == MODE_FWD) ? (SI == 0) : (SI == NSTEPS - 1);
+    constexpr bool to_hbm = (MODE == MODE_FWD) ? (SI == NSTEPS - 1) : (SI == 0);
+    constexpr bool twisted = COL && FLAG;
+    const AsmConsts c{a.f.N, a.f.negN, (u32)a.f.N, (u32)(a.f.N >> 32), (u32)a.f.Ninv,
+                      (u32)(a.f.Ninv >> 32), __builtin_amdgcn_read_exec()};
+    u64 x[E];
+    u32 I0[G], s_low[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const u32 s = tid + (u32)g * NT;
+      s_low[g] = s & ((1u << lo) - 1u);
+      I0[g] = ((s >> lo) << hi) | s_low[g];
+    }
+    u64 w0[8];  // first stage's twiddles: requested ahead of the data
+    stage_twiddles<k, LO, lo, 0>(a, s_low, w0);
+    // ---- gather ------------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if constexpr (from_hbm) {
+        const u64 vstride = COL ? (a.src_istride << LO) : (1ull << lo);
+        const u64 *p0 = a.src + saddr(a, t, I0[g]);
+#pragma unroll
+        for (int v = 0; v < R; ++v)
+          x[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
+      } else {
+        const u32 P0 = lds_phys(I0[g]);
+#pragma unroll
+        for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
+      }
+    }
+    if constexpr (twisted && MODE == MODE_INV && from_hbm) twist_all<k, LO>(a, t, x, I0, c);
+    // ---- k fused stages ------------------------------------------------------
+    stages_asm<k, LO, lo, 0>(a, x, s_low, w0, c);
+    // ---- scatter -------------------------------------------------------------
+    if constexpr (to_hbm) {
+      if constexpr (twisted && MODE == MODE_FWD) twist_all<k, LO>(a, t, x, I0, c);
+      if constexpr (!COL && FLAG && MODE == MODE_FWD) {
+        u64 op[E];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const u64 *e0 = a.epilogue + gaddr(a, t, I0[g]);
+#pragma unroll
+          for (int v = 0; v < R; ++v)
+            op[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? e0[(u64)v << lo] : 0;
+        }
+        MontGroup<0>::run(x, op[0], op[1], op[2], op[3], c);
+        MontGroup<1>::run(x, op[4], op[5], op[6], op[7], c);
+        MontGroup<2>::run(x, op[8], op[9], op[10], op[11], c);
+        MontGroup<3>::run(x, op[12], op[13], op[14], op[15], c);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
+        u64 *p0 = a.dst + gaddr(a, t, I0[g]);
+#pragma unroll
+        for (int v = 0; v < R; ++v)
+          if (in_range(a, t, I0[g] | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const u32 P0 = lds_phys(I0[g]);
+#pragma unroll
+        for (int v = 0; v < R; ++v) lds[P0 ^ lds_phys((u32)v << lo)] = x[g * R + v];
+      }
+    }
+  }
+
+  // x[i] *= omega_M^(bitrev_L(row) * column): both table halves of four elements are looked up,
+  // then composed and applied by one assembly group (twist_lookup + montmul of the C++ path)
+  template <int k, int LO, int GRP>
+  __device__ __forceinline__ static void twist_group(const PassArgs &a, const Tile &t, u64 (&x)[E],
+                                                     const u32 (&I0)[E >> k], const AsmConsts &c) {
+    constexpr int R = 1 << k;
+    u64 h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * GRP + q, g = i >> k, v = i & (R - 1);
+      const u32 col = twist_col(a, t, I0[g]);
+      const u32 e = twist_e0(col, I0[g]) + col * twist_bv(v, LO);
+      l[q] = a.twist_lo[e & ((1u << a.twist_shift) - 1u)];
+      h[q] = a.twist_hi[e >> a.twist_shift];
+    }
+    TwistGroup<GRP>::run(x, h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3], c);
+  }
+  template <int k, int LO>
+  __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
+                                                   const u32 (&I0)[E >> k], const AsmConsts &c) {
+    twist_group<k, LO, 0>(a, t, x, I0, c);
+    twist_group<k, LO, 1>(a, t, x, I0, c);
+    twist_group<k, LO, 2>(a, t, x, I0, c);
+    twist_group<k, LO, 3>(a, t, x, I0, c);
+  }
+
+  // twiddles of the eight butterflies of stage rr of the step (forward walks the stage bits
+  // downwards, inverse upwards); omega^0 entries of a lowest step are not loaded
+  template <int k, int LO, int lo, int rr>
+  __device__ __forceinline__ static void stage_twiddles(const PassArgs &a, const u32 (&s_low)[E >> k],
+                                                        u64 (&w)[8]) {
+    constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
+    constexpr int ps = LO + r;
+    const u64 *tab = a.stage_tw + ((1u << ps) - 1u);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = bf_first(r, b);
+      const int g = i >> k;
+      const u32 vlow = (u32)(i & ((1 << r) - 1));
+      const u32 j = ((vlow << lo) | s_low[g]) >> F0;
+      w[b] = (LO == 0 && vlow == 0) ? 0 : tab[j];
+    }
+  }
+
+  // stage rr with its twiddles in w; the next stage's are requested before the butterflies run
+  // so that their L2 latency hides behind ~300 VALU instructions
+  template <int k, int LO, int lo, int rr>
+  __device__ __forceinline__ static void stages_asm(const PassArgs &a, u64 (&x)[E], const u32 (&s_low)[E >> k],
+                                                    const u64 (&w)[8], const AsmConsts &c) {
+    constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
+    constexpr int ps = LO + r;
+    constexpr bool triv = (LO == 0);
+    u64 wn[8];
+    if constexpr (rr + 1 < k) stage_twiddles<k, LO, lo, rr + 1>(a, s_low, wn);
+    if constexpr (!COL && FLAG && MODE == MODE_INV && ps == LOGL - 1) {
+      // fold 1/L into the top stage: (c*x0) +- (c*w)*x1, the table holds c*w
+      ScaleGroup<r, 0>::run(x, a.scale, c);
+      ScaleGroup<r, 1>::run(x, a.scale, c);
+    }
+    BflyGroup<MODE, r, 0, triv>::run(x, w[0], w[1], w[2], w[3], c);
+    BflyGroup<MODE, r, 1, triv>::run(x, w[4], w[5], w[6], w[7], c);
+    if constexpr (rr + 1 < k) stages_asm<k, LO, lo, rr + 1>(a, x, s_low, wn, c);
+  }
+#endif  // SVENTT_STAGE_ASM
+
   // One step for one thread.  `first`/`last` say whether this step touches HBM.
   template <int SI>
   F64_HD static void step(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
+#if defined(SVENTT_STAGE_ASM)
+    if constexpr (LOGE == 4) {
+      step_asm<SI>(a, t, tid, lds);
+      return;
+    }
+#endif
     constexpr int k = STEPS::k[SI];
     constexpr int HI = LOGL - STEPS::sum(SI);  // field-relative top bit (exclusive)
     constexpr int LO = HI - k;
