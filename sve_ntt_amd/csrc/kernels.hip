@@ -14,13 +14,14 @@ template <class TN, int IDX>
 __device__ __forceinline__ void run_steps(const PassArgs &a, const typename TN::Tile &t, u32 tid,
                                           u64 *lds) {
   constexpr int SI = (TN::MODE == MODE_FWD) ? IDX : TN::NSTEPS - 1 - IDX;
-  if constexpr (IDX > 0) __syncthreads();
-  TN::template step<SI>(a, t, tid, lds);
+  TN::template step<SI, (IDX > 0)>(a, t, tid, lds);
   if constexpr (IDX + 1 < TN::NSTEPS) run_steps<TN, IDX + 1>(a, t, tid, lds);
 }
 
+// E = 16 tiles are sized for four waves per SIMD (two 512-thread workgroups per CU with their
+// 64 KiB tiles, or four 256-thread ones): keep the register allocator inside 128 VGPRs.
 template <class TN>
-__global__ __launch_bounds__(TN::NT) void tile_kernel(const PassArgs a) {
+__global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1) void tile_kernel(const PassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *lds = reinterpret_cast<u64 *>(smem);
   const typename TN::Tile t = TN::locate(a, blockIdx.x);

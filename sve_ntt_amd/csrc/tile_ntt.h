@@ -204,9 +204,69 @@ struct TileNTT {
   // first element of the b-th butterfly (ascending) of stage bit r over 16 registers
   static constexpr int bf_first(int r, int b) { return ((b >> r) << (r + 1)) | (b & ((1 << r) - 1)); }
 
+  // Looked-up halves of the twist factors of four elements (x[4 GRP .. 4 GRP + 3]).
+  struct TwistFactors {
+    u64 h[4], l[4];
+  };
+  template <int k, int LO, int GRP>
+  __device__ __forceinline__ static TwistFactors twist_load(const PassArgs &a, const Tile &t,
+                                                            const u32 (&I0)[E >> k]) {
+    constexpr int R = 1 << k;
+    TwistFactors f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * GRP + q, g = i >> k, v = i & (R - 1);
+      const u32 col = twist_col(a, t, I0[g]);
+      const u32 e = twist_e0(col, I0[g]) + col * twist_bv(v, LO);
+      f.l[q] = a.twist_lo[e & ((1u << a.twist_shift) - 1u)];
+      f.h[q] = a.twist_hi[e >> a.twist_shift];
+    }
+    return f;
+  }
+  // x[4 GRP + q] *= h[q] * l[q]   (twist_lookup + montmul of the C++ path, one assembly group)
+  template <int GRP>
+  __device__ __forceinline__ static void twist_apply(u64 (&x)[E], const TwistFactors &f, const AsmConsts &c) {
+    TwistGroup<GRP>::run(x, f.h[0], f.h[1], f.h[2], f.h[3], f.l[0], f.l[1], f.l[2], f.l[3], c);
+  }
+  // all 16 elements; the factors of group g + 1 are requested before group g's ~230 VALU
+  // instructions run.  `f0` holds group 0's, requested by the caller.
+  template <int k, int LO>
+  __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
+                                                   const u32 (&I0)[E >> k], const TwistFactors &f0,
+                                                   const AsmConsts &c) {
+    const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
+    twist_apply<0>(x, f0, c);
+    const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
+    twist_apply<1>(x, f1, c);
+    const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
+    twist_apply<2>(x, f2, c);
+    twist_apply<3>(x, f3, c);
+  }
+
+  // Operands of the fused pointwise product (ROW forward with FLAG) for x[4 GRP .. 4 GRP + 3].
+  struct Operands {
+    u64 v[4];
+  };
+  template <int k, int LO, int GRP>
+  __device__ __forceinline__ static Operands epilogue_load(const PassArgs &a, const Tile &t,
+                                                           const u32 (&I0)[E >> k]) {
+    constexpr int R = 1 << k, lo = F0 + LO;
+    Operands o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * GRP + q, g = i >> k, v = i & (R - 1);
+      const u32 I = I0[g] | ((u32)v << lo);
+      o.v[q] = in_range(a, t, I) ? a.epilogue[gaddr(a, t, I)] : 0;
+    }
+    return o;
+  }
+
   // The same step with all G sets of the thread held at once (x[g*R + v]) and the stages run
-  // by the assembly groups of stage_asm.inc, four butterflies per statement.
-  template <int SI>
+  // by the assembly groups of stage_asm.inc, four butterflies per statement.  Loads are issued
+  // in source order between the (volatile) assembly statements, so everything that comes from
+  // a table is requested one statement group ahead of its use.  SYNC: the step reads what the
+  // previous step wrote to LDS; the barrier comes after the first twiddle requests.
+  template <int SI, bool SYNC>
   __device__ __forceinline__ static void step_asm(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
     constexpr int k = STEPS::k[SI];
     constexpr int HI = LOGL - STEPS::sum(SI);
@@ -217,7 +277,9 @@ struct TileNTT {
     static_assert(E == 16, "assembly stages are generated for 16 elements per thread");
     constexpr bool from_hbm = (MODE == MODE_FWD) ? (SI == 0) : (SI == NSTEPS - 1);
     constexpr bool to_hbm = (MODE == MODE_FWD) ? (SI == NSTEPS - 1) : (SI == 0);
-    constexpr bool twisted = COL && FLAG;
+    constexpr bool twist_in = COL && FLAG && MODE == MODE_INV && from_hbm;
+    constexpr bool twist_out = COL && FLAG && MODE == MODE_FWD && to_hbm;
+    constexpr bool multiply_out = !COL && FLAG && MODE == MODE_FWD && to_hbm;
     const AsmConsts c{a.f.N, a.f.negN, (u32)a.f.N, (u32)(a.f.N >> 32), (u32)a.f.Ninv,
                       (u32)(a.f.Ninv >> 32), __builtin_amdgcn_read_exec()};
     u64 x[E];
@@ -228,8 +290,9 @@ struct TileNTT {
       s_low[g] = s & ((1u << lo) - 1u);
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
-    u64 w0[8];  // first stage's twiddles: requested ahead of the data
+    u64 w0[8];  // first stage's twiddles: requested ahead of the barrier and of the data
     stage_twiddles<k, LO, lo, 0>(a, s_low, w0);
+    if constexpr (SYNC) __syncthreads();
     // ---- gather ------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -245,25 +308,22 @@ struct TileNTT {
         for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
       }
     }
-    if constexpr (twisted && MODE == MODE_INV && from_hbm) twist_all<k, LO>(a, t, x, I0, c);
+    if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), c);
     // ---- k fused stages ------------------------------------------------------
-    stages_asm<k, LO, lo, 0>(a, x, s_low, w0, c);
+    TwistFactors f0;
+    Operands o0;
+    stages_asm<k, LO, lo, 0, twist_out, multiply_out>(a, t, x, I0, s_low, w0, f0, o0, c);
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
-      if constexpr (twisted && MODE == MODE_FWD) twist_all<k, LO>(a, t, x, I0, c);
-      if constexpr (!COL && FLAG && MODE == MODE_FWD) {
-        u64 op[E];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const u64 *e0 = a.epilogue + gaddr(a, t, I0[g]);
-#pragma unroll
-          for (int v = 0; v < R; ++v)
-            op[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? e0[(u64)v << lo] : 0;
-        }
-        MontGroup<0>::run(x, op[0], op[1], op[2], op[3], c);
-        MontGroup<1>::run(x, op[4], op[5], op[6], op[7], c);
-        MontGroup<2>::run(x, op[8], op[9], op[10], op[11], c);
-        MontGroup<3>::run(x, op[12], op[13], op[14], op[15], c);
+      if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, c);
+      if constexpr (multiply_out) {
+        const Operands o1 = epilogue_load<k, LO, 1>(a, t, I0);
+        MontGroup<0>::run(x, o0.v[0], o0.v[1], o0.v[2], o0.v[3], c);
+        const Operands o2 = epilogue_load<k, LO, 2>(a, t, I0);
+        MontGroup<1>::run(x, o1.v[0], o1.v[1], o1.v[2], o1.v[3], c);
+        const Operands o3 = epilogue_load<k, LO, 3>(a, t, I0);
+        MontGroup<2>::run(x, o2.v[0], o2.v[1], o2.v[2], o2.v[3], c);
+        MontGroup<3>::run(x, o3.v[0], o3.v[1], o3.v[2], o3.v[3], c);
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -281,32 +341,6 @@ struct TileNTT {
         for (int v = 0; v < R; ++v) lds[P0 ^ lds_phys((u32)v << lo)] = x[g * R + v];
       }
     }
-  }
-
-  // x[i] *= omega_M^(bitrev_L(row) * column): both table halves of four elements are looked up,
-  // then composed and applied by one assembly group (twist_lookup + montmul of the C++ path)
-  template <int k, int LO, int GRP>
-  __device__ __forceinline__ static void twist_group(const PassArgs &a, const Tile &t, u64 (&x)[E],
-                                                     const u32 (&I0)[E >> k], const AsmConsts &c) {
-    constexpr int R = 1 << k;
-    u64 h[4], l[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 4 * GRP + q, g = i >> k, v = i & (R - 1);
-      const u32 col = twist_col(a, t, I0[g]);
-      const u32 e = twist_e0(col, I0[g]) + col * twist_bv(v, LO);
-      l[q] = a.twist_lo[e & ((1u << a.twist_shift) - 1u)];
-      h[q] = a.twist_hi[e >> a.twist_shift];
-    }
-    TwistGroup<GRP>::run(x, h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3], c);
-  }
-  template <int k, int LO>
-  __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
-                                                   const u32 (&I0)[E >> k], const AsmConsts &c) {
-    twist_group<k, LO, 0>(a, t, x, I0, c);
-    twist_group<k, LO, 1>(a, t, x, I0, c);
-    twist_group<k, LO, 2>(a, t, x, I0, c);
-    twist_group<k, LO, 3>(a, t, x, I0, c);
   }
 
   // twiddles of the eight butterflies of stage rr of the step (forward walks the stage bits
@@ -328,15 +362,21 @@ struct TileNTT {
   }
 
   // stage rr with its twiddles in w; the next stage's are requested before the butterflies run
-  // so that their L2 latency hides behind ~300 VALU instructions
-  template <int k, int LO, int lo, int rr>
-  __device__ __forceinline__ static void stages_asm(const PassArgs &a, u64 (&x)[E], const u32 (&s_low)[E >> k],
-                                                    const u64 (&w)[8], const AsmConsts &c) {
+  // so that their L2 latency hides behind ~300 VALU instructions.  Ahead of the step's last
+  // stage the first group of what the scatter multiplies by is requested too (TW: twist
+  // factors into f0, MUL: operands of the fused product into o0).
+  template <int k, int LO, int lo, int rr, bool TW, bool MUL>
+  __device__ __forceinline__ static void stages_asm(const PassArgs &a, const Tile &t, u64 (&x)[E],
+                                                    const u32 (&I0)[E >> k], const u32 (&s_low)[E >> k],
+                                                    const u64 (&w)[8], TwistFactors &f0, Operands &o0,
+                                                    const AsmConsts &c) {
     constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
     constexpr int ps = LO + r;
     constexpr bool triv = (LO == 0);
     u64 wn[8];
     if constexpr (rr + 1 < k) stage_twiddles<k, LO, lo, rr + 1>(a, s_low, wn);
+    if constexpr (rr + 1 == k && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
+    if constexpr (rr + 1 == k && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
     if constexpr (!COL && FLAG && MODE == MODE_INV && ps == LOGL - 1) {
       // fold 1/L into the top stage: (c*x0) +- (c*w)*x1, the table holds c*w
       ScaleGroup<r, 0>::run(x, a.scale, c);
@@ -344,18 +384,22 @@ struct TileNTT {
     }
     BflyGroup<MODE, r, 0, triv>::run(x, w[0], w[1], w[2], w[3], c);
     BflyGroup<MODE, r, 1, triv>::run(x, w[4], w[5], w[6], w[7], c);
-    if constexpr (rr + 1 < k) stages_asm<k, LO, lo, rr + 1>(a, x, s_low, wn, c);
+    if constexpr (rr + 1 < k) stages_asm<k, LO, lo, rr + 1, TW, MUL>(a, t, x, I0, s_low, wn, f0, o0, c);
   }
 #endif  // SVENTT_STAGE_ASM
 
   // One step for one thread.  `first`/`last` say whether this step touches HBM.
-  template <int SI>
+  // SYNC (device only): a workgroup barrier separates this step from the previous one.
+  template <int SI, bool SYNC = false>
   F64_HD static void step(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
 #if defined(SVENTT_STAGE_ASM)
     if constexpr (LOGE == 4) {
-      step_asm<SI>(a, t, tid, lds);
+      step_asm<SI, SYNC>(a, t, tid, lds);
       return;
     }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SYNC) __syncthreads();
 #endif
     constexpr int k = STEPS::k[SI];
     constexpr int HI = LOGL - STEPS::sum(SI);  // field-relative top bit (exclusive)
