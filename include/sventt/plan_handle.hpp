@@ -34,11 +34,15 @@ template <class kernel_type> sventt_plan *create_plan(const std::uint32_t flags)
   using modulus_type = typename kernel_type::modulus_type;
   sventt_plan *plan{};
   constexpr std::uint32_t rows_log2{requested_rows_log2<kernel_type>()};
-  int status{sventt_plan_create(modulus_type::get_modulus(), modulus_type::get_generator(),
-                                kernel_type::get_m(), rows_log2, 1, flags, &plan)};
+  // the inverse divides by the product of the layers' inverse_factor arguments: 1 (no
+  // scaling) for README-shaped kernels, m for kernels whose last layer ends in `..., m>`
+  constexpr std::uint64_t inverse_divisor{kernel_type::get_inverse_factor()};
+  static_assert(inverse_divisor != 0, "an inverse_factor is a multiple of the modulus");
+  int status{sventt_plan_create_ex(modulus_type::get_modulus(), modulus_type::get_generator(),
+                                   kernel_type::get_m(), rows_log2, 1, flags, inverse_divisor, &plan)};
   if (status == SVENTT_ERR_INVALID_ARGUMENT && rows_log2 != 0) {
-    status = sventt_plan_create(modulus_type::get_modulus(), modulus_type::get_generator(),
-                                kernel_type::get_m(), 0, 1, flags, &plan);
+    status = sventt_plan_create_ex(modulus_type::get_modulus(), modulus_type::get_generator(),
+                                   kernel_type::get_m(), 0, 1, flags, inverse_divisor, &plan);
   }
   throw_on_error(status);
   return plan;

@@ -119,6 +119,8 @@ template <class modmul_type_, std::uint64_t m, class inner_kernel_type_> struct 
   static_assert(m % inner_kernel_type::get_m() == 0);
   static constexpr std::uint64_t get_m(void) { return m; }
   static constexpr std::uint64_t get_radix(void) { return inner_kernel_type::get_m(); }
+  // a six-step layer has no inverse_factor of its own; its inner kernel's layers may
+  static constexpr std::uint64_t get_inverse_factor(void) { return inner_kernel_type::get_inverse_factor(); }
   static constexpr bool is_six_step_layer{true};
   class buffer_type {};  // scratch lived here in the reference; the GPU passes need none
 };
@@ -211,6 +213,14 @@ public:
   static constexpr std::uint64_t get_span(void) { return radix_product; }
   // no preferred split: the engine plans the decomposition itself
   static constexpr std::uint64_t get_six_step_rows(void) { return 0; }
+  // What the inverse divides by: every layer with inverse_factor != 1 multiplies by its
+  // modular inverse (layer/sve/radix-two.hpp:208-235 of the reference), so the kernel as a
+  // whole scales by the inverse of the product (mod p).  1 = unscaled (README.md:36-68).
+  static constexpr std::uint64_t get_inverse_factor(void) {
+    std::uint64_t f{1};
+    ((f = modulus_type::multiply(f, layer_types::get_inverse_factor() % modulus_type::get_modulus())), ...);
+    return f;
+  }
 };
 
 // RecursiveNTT<modulus, m, layer, inner_kernel, separate_twiddle>: one outer layer
@@ -244,6 +254,12 @@ public:
   // R of the six-step split n = R x C when the user spelled one out
   static constexpr std::uint64_t get_six_step_rows(void) {
     return (separate_twiddle || layer_type::is_six_step_layer) ? layer_type::get_radix() : 0;
+  }
+  // product of the inverse factors of the outer layer (and, for a six-step layer, of its
+  // column kernel) and of the inner kernel: see IterativeNTT::get_inverse_factor
+  static constexpr std::uint64_t get_inverse_factor(void) {
+    return modulus_type::multiply(layer_type::get_inverse_factor() % modulus_type::get_modulus(),
+                                  inner_kernel_type::get_inverse_factor());
   }
 };
 

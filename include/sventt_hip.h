@@ -55,8 +55,22 @@ enum {
 enum {
   SVENTT_FORWARD = 1u, /* NTT(enable_forward=true, ...)   wrapper.hpp:34 */
   SVENTT_INVERSE = 2u, /* NTT(..., enable_inverse=true)   wrapper.hpp:34 */
-  SVENTT_BOTH = 3u
+  SVENTT_BOTH = 3u,
+  SVENTT_DEVICE_POINTERS = 4u /* every dst/src/operand ever passed with this plan is memory of the
+                                 plan's device: the calls skip hipPointerGetAttributes (two driver
+                                 queries per transform, a visible share of a 10 us small transform) */
 };
+
+/*
+ * Threads and devices.  A plan belongs to the HIP device that was current when it was
+ * created (sventt_plan_device); calls with it must come from threads whose current device is
+ * that one and take memory of that device, otherwise they return SVENTT_ERR_INVALID_ARGUMENT.
+ * A plan is immutable once created: any number of threads may use one plan concurrently with
+ * device pointers (the reference's compute_* are const and re-entrant the same way,
+ * wrapper.hpp:50-82).  Host-pointer calls on the SAME plan take turns on its one staging
+ * buffer (they block each other, results stay correct); use one plan per thread to overlap them.
+ * p must be prime (checked: deterministic Miller-Rabin).
+ */
 
 /*
  * Replaces the construction of sventt::NTT<kernel_type> (wrapper.hpp:34-46:
@@ -70,6 +84,23 @@ enum {
  */
 int sventt_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2,
                        uint64_t batch, uint32_t flags, sventt_plan **plan);
+
+/*
+ * The same with the inverse's scaling spelled out: the inverse transform multiplies its
+ * result by inverse_divisor^{-1} mod p.  0 = n (what sventt_plan_create does: the oracle's
+ * inverse, tests/ntt-reference.hpp:78-82); 1 = no scaling.  This is the product of the
+ * `inverse_factor` template arguments of the reference's layers: a layer with
+ * inverse_factor != 1 multiplies by its modular inverse (layer/sve/radix-two.hpp:208-235,
+ * 307-328 and the radix-4/8 siblings), so README.md:36-68-shaped kernels (no inverse_factor)
+ * return the UNSCALED inverse and kernels whose last layer ends in `..., m>`
+ * (tests/ntt-tests/iterative-sve-radix8-two12.hpp:17) divide by m.
+ */
+int sventt_plan_create_ex(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2,
+                          uint64_t batch, uint32_t flags, uint64_t inverse_divisor,
+                          sventt_plan **plan);
+
+/* HIP device ordinal the plan's tables live on (-1 for a null plan). */
+int sventt_plan_device(const sventt_plan *plan);
 
 void sventt_plan_destroy(sventt_plan *plan);
 

@@ -105,22 +105,29 @@ class NTT:
 
     ``m`` is the transform length (``get_m()``), ``n0_log2`` the column length of
     the six-step split (0 = automatic), ``batch`` the number of back-to-back
-    independent transforms (the reference's API is batch 1).
+    independent transforms (the reference's API is batch 1).  ``inverse_divisor``:
+    the inverse multiplies by its modular inverse -- 0 = m (the oracle's 1/m),
+    1 = unscaled (what the reference's layers compute when none carries an
+    ``inverse_factor``, layer/sve/radix-two.hpp:208-235).  ``device_pointers``:
+    promise that every buffer is memory of the plan's device (skips the
+    pointer-kind queries of each call).
     """
 
     def __init__(self, modulus: Modulus, m: int, n0_log2: int = 0, batch: int = 1,
                  enable_forward: bool = True, enable_inverse: bool = True,
-                 allocate_huge_pages: bool = True):
+                 allocate_huge_pages: bool = True, inverse_divisor: int = 0,
+                 device_pointers: bool = False):
         del allocate_huge_pages  # accepted for signature parity; device tables need no huge pages
         self._lib = _lib.load()
         self.modulus_type = modulus
         self._m = m
         self._batch = batch
         flags = (_lib.SVENTT_FORWARD if enable_forward else 0) | (
-            _lib.SVENTT_INVERSE if enable_inverse else 0)
+            _lib.SVENTT_INVERSE if enable_inverse else 0) | (
+            _lib.SVENTT_DEVICE_POINTERS if device_pointers else 0)
         h = ctypes.c_void_p()
-        _lib.check(self._lib.sventt_plan_create(modulus.modulus, modulus.generator, m, n0_log2,
-                                                batch, flags, ctypes.byref(h)))
+        _lib.check(self._lib.sventt_plan_create_ex(modulus.modulus, modulus.generator, m, n0_log2,
+                                                   batch, flags, inverse_divisor, ctypes.byref(h)))
         self._h = h
 
     def __del__(self):

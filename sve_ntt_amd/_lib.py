@@ -22,6 +22,7 @@ SVENTT_ERR_NO_DEVICE = -5
 SVENTT_FORWARD = 1
 SVENTT_INVERSE = 2
 SVENTT_BOTH = 3
+SVENTT_DEVICE_POINTERS = 4
 
 # name -> (restype, argtypes); must list every symbol include/sventt_hip.h declares
 _u64 = ctypes.c_uint64
@@ -30,6 +31,8 @@ _vp = ctypes.c_void_p
 _int = ctypes.c_int
 SYMBOLS = {
     "sventt_plan_create": (_int, [_u64, _u64, _u64, _u32, _u64, _u32, ctypes.POINTER(_vp)]),
+    "sventt_plan_create_ex": (_int, [_u64, _u64, _u64, _u32, _u64, _u32, _u64, ctypes.POINTER(_vp)]),
+    "sventt_plan_device": (_int, [_vp]),
     "sventt_plan_destroy": (None, [_vp]),
     "sventt_forward": (_int, [_vp, _vp, _vp, _vp]),
     "sventt_inverse": (_int, [_vp, _vp, _vp, _vp]),

@@ -5,6 +5,8 @@
 // layer/sve/blocked-generic.hpp:139-154, or one row in kernel/recursive.hpp:69-74).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "kernels.h"
 #include "tile_ntt.h"
 
@@ -32,12 +34,20 @@ __global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1) vo
 template <class TN>
 static hipError_t launch_tile(const PassArgs &a, u32 grid, hipStream_t stream) {
   constexpr size_t lds_bytes = (TN::NSTEPS > 1) ? (sizeof(u64) << TN::LOGT) : 0;
-  static bool attr_set = false;
-  if (lds_bytes > 48 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel<TN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if constexpr (lds_bytes > 48 * 1024) {
+    // the opt-in to more than 48 KiB of dynamic LDS is a per-device property of the function:
+    // one bit per device ordinal, set once the attribute call succeeded there
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel<TN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+      done.fetch_or(bit, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(tile_kernel<TN>, dim3(grid), dim3(TN::NT), lds_bytes, stream, a);
   return hipGetLastError();

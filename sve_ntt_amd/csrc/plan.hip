@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -51,7 +52,11 @@ struct sventt_plan {
   HostPlan host;
   std::vector<DevicePass> fwd, inv;
   std::string description;
-  // staging for host-pointer calls
+  int device = -1;              // the HIP device whose memory holds the tables
+  bool device_pointers = false; // SVENTT_DEVICE_POINTERS: never classify dst/src
+  // staging for host-pointer calls: one buffer per plan, so such calls on one plan take turns
+  // (the mutex is held from the upload to the end of the download)
+  mutable std::mutex staging_mutex;
   mutable u64 *staging = nullptr;
   mutable size_t staging_elems = 0;
 };
@@ -90,6 +95,11 @@ int finish_plan(sventt_plan *pl, int rc, const std::string &err, sventt_plan **o
     delete pl;
     return fail(rc == PLAN_ERR_INVALID_ARGUMENT ? SVENTT_ERR_INVALID_ARGUMENT : SVENTT_ERR_LOGIC, err);
   }
+  if (hipGetDevice(&pl->device) != hipSuccess) {
+    delete pl;
+    return fail(SVENTT_ERR_HIP, "hipGetDevice failed");
+  }
+  pl->device_pointers = (pl->host.flags & SVENTT_DEVICE_POINTERS) != 0;
   if ((rc = realize(pl->host.fwd, pl->fwd)) || (rc = realize(pl->host.inv, pl->inv))) {
     sventt_plan_destroy(pl);
     return rc;
@@ -111,23 +121,42 @@ int run_pass(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const 
   return SVENTT_OK;
 }
 
-bool is_device_pointer(const void *p) {
+// device: if non-null, receives the ordinal of the device that owns the memory (-1: host)
+bool is_device_pointer(const void *p, int *device = nullptr) {
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (device) *device = -1;
   if (e != hipSuccess) {
     (void)hipGetLastError();  // plain host memory: clear the sticky error
     return false;
   }
-  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
-         attr.type == hipMemoryTypeArray;
+  const bool dev = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
+                   attr.type == hipMemoryTypeArray;
+  if (dev && device) *device = attr.device;
+  return dev;
+}
+
+// The kernels run on the current device and read the plan's tables there.
+int check_current_device(const sventt_plan *pl) {
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != pl->device)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT,
+                "the plan was created on HIP device " + std::to_string(pl->device) +
+                    " but the calling thread's current device is " + std::to_string(cur));
+  return SVENTT_OK;
 }
 
 int transform_device(const sventt_plan *pl, bool inverse, u64 *dst, const u64 *src,
                      hipStream_t stream) {
   const size_t npass = (inverse ? pl->inv : pl->fwd).size();
   if (pl->host.n == 1) {
-    if (dst != src)
+    if (inverse && pl->host.inverse_scale != 1) {
+      HIP_TRY(launch_montmul(dst, src, nullptr, h_to_montgomery(pl->host.inverse_scale, pl->host.f.N),
+                             pl->host.total, pl->host.f, stream));
+    } else if (dst != src) {
       HIP_TRY(hipMemcpyAsync(dst, src, pl->host.total * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    }
     return SVENTT_OK;
   }
   const u64 *in = src;
@@ -146,12 +175,22 @@ int transform(const sventt_plan *pl, bool inverse, u64 *dst, const u64 *src, voi
     return fail(SVENTT_ERR_LOGIC, inverse ? "plan was created without SVENTT_INVERSE"
                                           : "plan was created without SVENTT_FORWARD");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const bool ddst = is_device_pointer(dst), dsrc = is_device_pointer(src);
-  if (ddst && dsrc) return transform_device(pl, inverse, dst, src, stream);
+  int rc = check_current_device(pl);
+  if (rc) return rc;
+  if (pl->device_pointers) return transform_device(pl, inverse, dst, src, stream);
+  int dev_dst = -1, dev_src = -1;
+  const bool ddst = is_device_pointer(dst, &dev_dst), dsrc = is_device_pointer(src, &dev_src);
+  if (ddst && dsrc) {
+    if (dev_dst != pl->device || dev_src != pl->device)
+      return fail(SVENTT_ERR_INVALID_ARGUMENT, "dst/src live on another HIP device than the plan");
+    return transform_device(pl, inverse, dst, src, stream);
+  }
   if (ddst != dsrc)
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "dst and src must both be device or both be host pointers");
   // Host pointers (what NTT::compute_* of the reference take, wrapper.hpp:50-82):
-  // stage through a plan-owned device buffer; returns when dst is complete.
+  // stage through a plan-owned device buffer; returns when dst is complete.  Calls on the
+  // same plan serialise here (one staging buffer per plan).
+  std::lock_guard<std::mutex> lock(pl->staging_mutex);
   const size_t bytes = pl->host.total * sizeof(u64);
   if (pl->staging_elems < pl->host.total) {
     if (pl->staging) (void)hipFree(pl->staging);
@@ -161,7 +200,7 @@ int transform(const sventt_plan *pl, bool inverse, u64 *dst, const u64 *src, voi
     pl->staging_elems = pl->host.total;
   }
   HIP_TRY(hipMemcpyAsync(pl->staging, src, bytes, hipMemcpyHostToDevice, stream));
-  int rc = transform_device(pl, inverse, pl->staging, pl->staging, stream);
+  rc = transform_device(pl, inverse, pl->staging, pl->staging, stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(dst, pl->staging, bytes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -172,20 +211,27 @@ int transform(const sventt_plan *pl, bool inverse, u64 *dst, const u64 *src, voi
 
 extern "C" {
 
-int sventt_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch,
-                       uint32_t flags, sventt_plan **out) {
+int sventt_plan_create_ex(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch,
+                          uint32_t flags, uint64_t inverse_divisor, sventt_plan **out) {
   if (!out) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null plan pointer");
   *out = nullptr;
   sventt_plan *pl = new (std::nothrow) sventt_plan;
   if (!pl) return fail(SVENTT_ERR_ALLOC, "out of host memory");
   std::string err;
-  int rc = build_plan(pl->host, p, g, n, n0_log2, batch, flags, err);
+  int rc = build_plan(pl->host, p, g, n, n0_log2, batch, flags, err, inverse_divisor);
   if (!rc && check_device()) {
     delete pl;
     return SVENTT_ERR_NO_DEVICE;
   }
   return finish_plan(pl, rc, err, out);
 }
+
+int sventt_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch,
+                       uint32_t flags, sventt_plan **out) {
+  return sventt_plan_create_ex(p, g, n, n0_log2, batch, flags, 0, out);
+}
+
+int sventt_plan_device(const sventt_plan *pl) { return pl ? pl->device : -1; }
 
 int sventt_sharded_plan_create(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int rank,
                                int nranks, uint32_t flags, sventt_plan **out) {
@@ -297,7 +343,7 @@ const char *sventt_plan_describe(const sventt_plan *pl) { return pl ? pl->descri
 int sventt_pointwise_multiply(const sventt_plan *pl, uint64_t *dst, const uint64_t *a,
                               const uint64_t *b, uint64_t count, void *stream) {
   if (!pl || !dst || !a || !b) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
-  if (!is_device_pointer(dst) || !is_device_pointer(a) || !is_device_pointer(b))
+  if (!pl->device_pointers && (!is_device_pointer(dst) || !is_device_pointer(a) || !is_device_pointer(b)))
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "pointwise multiply takes device pointers");
   HIP_TRY(launch_pointwise(dst, a, b, count, pl->host.f, pl->host.r2,
                            static_cast<hipStream_t>(stream)));
@@ -309,7 +355,8 @@ int sventt_forward_multiply(const sventt_plan *pl, uint64_t *dst, const uint64_t
   if (!pl || !dst || !src || !operand) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
   if (pl->host.sharded) return fail(SVENTT_ERR_LOGIC, "not available on sharded plans");
   if (!(pl->host.flags & PLAN_FORWARD)) return fail(SVENTT_ERR_LOGIC, "plan was created without SVENTT_FORWARD");
-  if (!is_device_pointer(dst) || !is_device_pointer(src) || !is_device_pointer(operand))
+  if (!pl->device_pointers &&
+      (!is_device_pointer(dst) || !is_device_pointer(src) || !is_device_pointer(operand)))
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "the fused forward-multiply takes device pointers");
   if (operand == dst) return fail(SVENTT_ERR_INVALID_ARGUMENT, "operand must not alias dst");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -336,7 +383,7 @@ int sventt_forward_multiply(const sventt_plan *pl, uint64_t *dst, const uint64_t
 static int convert_domain(const sventt_plan *pl, uint64_t *dst, const uint64_t *src, uint64_t count,
                           u64 factor, void *stream) {
   if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
-  if (!is_device_pointer(dst) || !is_device_pointer(src))
+  if (!pl->device_pointers && (!is_device_pointer(dst) || !is_device_pointer(src)))
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "domain conversion takes device pointers");
   HIP_TRY(launch_montmul(dst, src, nullptr, factor, count, pl->host.f, static_cast<hipStream_t>(stream)));
   return SVENTT_OK;

@@ -47,6 +47,7 @@ struct HostPlan {
   u64 g = 0, n = 0, batch = 1, total = 0;
   u32 flags = 0;
   u64 r2 = 0;  // 2^128 mod N
+  u64 inverse_scale = 1;  // what the inverse multiplies by (plain residue): n^{-1} unless asked otherwise
   std::vector<HostPass> fwd, inv;
   bool fine = false;  // E = 4 tiles (registry.h): n * batch too small to fill the chip otherwise
   bool sharded = false;
@@ -59,7 +60,7 @@ enum : int {
   PLAN_ERR_INVALID_ARGUMENT = -1,
   PLAN_ERR_LOGIC = -4,
 };
-enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u };
+enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u, PLAN_DEVICE_POINTERS = 4u, PLAN_KNOWN_FLAGS = 7u };
 
 // Tuning knobs (environment, read once).  SVENTT_COL_SLIM=0/1: 4-column instead of
 // 8-column tiles for column passes of length >= 2^10 (two workgroups per CU).
@@ -248,8 +249,33 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
   return PLAN_OK;
 }
 
+// Deterministic Miller-Rabin for 64-bit integers (the twelve smallest primes as witnesses
+// decide every n < 3.3 * 10^24).  The tables are built with Fermat inverses, so a composite
+// modulus would yield garbage silently; the reference's Modulus<p, g> is equally only
+// meaningful for primes (modulus.hpp:14).
+inline bool is_prime_u64(u64 n) {
+  if (n < 2) return false;
+  for (u64 q : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+    if (n % q == 0) return n == q;
+  }
+  u64 d = n - 1;
+  int s = 0;
+  while ((d & 1) == 0) d >>= 1, ++s;
+  for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+    u64 x = h_powmod(a, d, n);
+    if (x == 1 || x == n - 1) continue;
+    bool composite = true;
+    for (int i = 1; i < s && composite; ++i) {
+      x = h_mulmod(x, x, n);
+      if (x == n - 1) composite = false;
+    }
+    if (composite) return false;
+  }
+  return true;
+}
+
 inline int validate_field(u64 p, u64 g, u64 n, std::string &err) {
-  if (p < 3 || (p & 1) == 0) {
+  if (p < 3 || (p & 1) == 0 || !is_prime_u64(p)) {
     err = "modulus must be an odd prime";
     return PLAN_ERR_INVALID_ARGUMENT;
   }
@@ -283,8 +309,12 @@ inline void init_field(HostPlan &pl, u64 p, u64 g) {
   pl.r2 = h_to_montgomery(h_to_montgomery(1, p), p);
 }
 
+// inverse_divisor: the inverse transform multiplies by inverse_divisor^{-1} mod p; 0 stands for n
+// (the oracle's 1/n, tests/ntt-reference.hpp:78-82), 1 for the unscaled inverse that the
+// reference's layers compute when no layer carries an inverse_factor (layer/sve/radix-two.hpp:
+// 208-235: only `inverse_factor != 1` adds the multiplication by its inverse).
 inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch, u32 flags,
-                      std::string &err) {
+                      std::string &err, u64 inverse_divisor = 0) {
   int rc = validate_field(p, g, n, err);
   if (rc) return rc;
   if (batch == 0) {
@@ -293,6 +323,10 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   }
   if ((flags & (PLAN_FORWARD | PLAN_INVERSE)) == 0) {
     err = "neither direction enabled";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  if (flags & ~PLAN_KNOWN_FLAGS) {
+    err = "unknown plan flag";
     return PLAN_ERR_INVALID_ARGUMENT;
   }
   if (n > (~0ull) / batch / 8) {
@@ -305,7 +339,15 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   pl.total = n * batch;
   pl.flags = flags;
   const int logn = ilog2_u64(n);
-  if (logn == 0) return PLAN_OK;
+  if (logn == 0) {  // length 1: the transform is the identity (times the inverse's scale)
+    const u64 d1 = inverse_divisor ? inverse_divisor % p : 1;
+    if (d1 == 0) {
+      err = "inverse divisor is a multiple of the modulus";
+      return PLAN_ERR_INVALID_ARGUMENT;
+    }
+    pl.inverse_scale = h_invmod(d1, p);
+    return PLAN_OK;
+  }
   std::vector<int> cols;
   int row = 0;
   // small totals run on the fine (E = 4) tiles, provided they cover the requested split
@@ -318,7 +360,13 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
               logn - (int)n0_log2 <= MAX_FINE_ROW_LOGL &&
               registry_fine_col_f0((int)n0_log2, logn - (int)n0_log2) >= 0;
   if ((rc = choose_split(logn, n0_log2, cols, row, err, pl.fine))) return rc;
-  const u64 ninv = h_invmod(n % p, p);
+  const u64 divisor = inverse_divisor ? inverse_divisor % p : n % p;
+  if (divisor == 0) {
+    err = "inverse divisor is a multiple of the modulus";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const u64 ninv = h_invmod(divisor, p);
+  pl.inverse_scale = ninv;
   if (flags & PLAN_FORWARD) {
     int rem = logn;
     for (size_t i = 0; i < cols.size(); ++i) {

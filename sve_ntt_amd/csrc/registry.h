@@ -45,8 +45,9 @@ template <> struct RowSteps<11> { using type = Steps<4, 4, 2, 1>; };
 constexpr int REG_LOGE = 4;
 // ROW tiles are 2^12 elements (256 threads) unless the row itself is longer.
 constexpr int row_logt(int logl) { return logl > 12 ? logl : 12; }
-// COL tiles hold T = 8 adjacent columns (64-byte HBM segments); short columns
-// afford more so that the tile still has 2^12 elements.
+// Wide COL tiles hold T = 8 adjacent columns (64-byte HBM segments), more for short columns so
+// that the tile still has 2^12 elements.  Columns of 2^10..2^12 default to the slim T = 4 tiles
+// below (plan_core.h: Tuning::col_slim); the wide ones remain for SVENTT_COL_SLIM=0.
 constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
 
 template <int LOGL, int MODE, bool FLAG>

@@ -1,6 +1,6 @@
 // sve_ntt_amd/csrc/tile_ntt.h -- one workgroup's share of an NTT pass.
 //
-// A pass of the plan (plan.h) cuts the data into TILES of 2^LOGT elements; one
+// A pass of the plan (plan_core.h) cuts the data into TILES of 2^LOGT elements; one
 // workgroup owns one tile for the whole pass: every element is read from HBM
 // once, all of the pass's butterfly stages run on chip, every element is
 // written once.  This is the GPU shape of the reference's per-thread
@@ -93,7 +93,7 @@ template <int... KS> struct Steps {
 
 // XOR swizzle of the LDS image: bank bits 0..4 (8-byte words) are mixed with
 // index bits 4..8 so that the strided element sets of every step fall on
-// distinct banks (checked by tests/test_lds_swizzle.py).
+// distinct banks (checked by tests/test_host_logic.py::test_lds_swizzle_is_a_bijection_and_conflict_free).
 F64_HD u32 lds_phys(u32 I) { return I ^ ((I >> 4) & 31u); }
 
 F64_HD u32 bitrev32(u32 x) {

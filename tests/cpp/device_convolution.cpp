@@ -58,13 +58,17 @@ using modmul_type = PAdic64SVE<modulus_type>;
 constexpr std::uint64_t N{modulus_type::get_modulus()}, g{modulus_type::get_generator()};
 
 // A kernel type that is valid by the reference's own rules (kernel/iterative.hpp:24-27):
-// log2(m) radix-2 layers of span m, m/2, ..., 2.  Only modulus and length reach the planner.
+// log2(m) radix-2 layers of span m, m/2, ..., 2; the last one carries inverse_factor = m so that
+// the inverse divides by m (layer/sve/radix-two.hpp:208-235 of the reference).  Modulus, length
+// and that factor reach the planner.
 template <std::uint64_t m, std::size_t... I>
 auto radix_two_chain(std::index_sequence<I...>)
-    -> IterativeNTT<modulus_type, m, RadixTwoSVELayer<modmul_type, m, (m >> I)>...>;
+    -> IterativeNTT<modulus_type, m,
+                    RadixTwoSVELayer<modmul_type, m, (m >> I), ((m >> I) == 2 ? m : 1)>...>;
 template <std::uint64_t m>
 using iterative = decltype(radix_two_chain<m>(std::make_index_sequence<std::bit_width(m) - 1>{}));
 static_assert(iterative<1024>::get_m() == 1024);
+static_assert(iterative<1024>::get_inverse_factor() == 1024);
 
 template <std::uint64_t m> static bool convolution_matches_oracle(void) {
   std::vector<std::uint64_t> a(m), b(m), fa(m), fb(m), prod(m), want(m);

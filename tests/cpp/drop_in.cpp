@@ -124,6 +124,17 @@ template <class kernel_type, bool is_inverse> static bool check(const char *name
     oracle_ntt_forward(ref, src, m, N, g);
   }
 
+  // The oracle's inverse divides by m (tests/ntt-reference.hpp:78-82); a kernel_type divides by
+  // the product of its layers' inverse_factor arguments (layer/sve/radix-two.hpp:208-235 of the
+  // reference): README-shaped kernels by 1 (unscaled), `..., m>`-terminated ones by m.
+  constexpr std::uint64_t divisor{kernel_type::get_inverse_factor()};
+  const std::uint64_t rescale{modulus_type::multiply(m % N, modulus_type::invert(divisor))};
+  if (is_inverse) {
+    for (std::uint64_t i{}; i < m; ++i) {
+      ref[i] = modulus_type::multiply(ref[i], rescale);
+    }
+  }
+
   const ntt_type ntt{!is_inverse, is_inverse, false};
   if (is_inverse) {
     ntt.compute_inverse(dst, src);
@@ -143,11 +154,14 @@ template <class kernel_type, bool is_inverse> static bool check(const char *name
   std::memcpy(dst, src, sizeof(std::uint64_t) * m);
   both.compute_forward(dst);
   both.compute_inverse(dst);
-  if (std::memcmp(dst, src, sizeof(std::uint64_t) * m) != 0) {
-    std::printf("MISMATCH round trip %s\n", name);
-    return false;
+  for (std::uint64_t i{}; i < m; ++i) {
+    if (dst[i] != modulus_type::multiply(src[i], rescale)) {
+      std::printf("MISMATCH round trip %s at %llu\n", name, static_cast<unsigned long long>(i));
+      return false;
+    }
   }
-  std::printf("ok %s %s  [%s]\n", is_inverse ? "Inverse," : "Forward,", name, ntt.describe().c_str());
+  std::printf("ok %s %s  [%s] (inverse divides by %llu)\n", is_inverse ? "Inverse," : "Forward,", name,
+              ntt.describe().c_str(), static_cast<unsigned long long>(divisor));
   return true;
 }
 
@@ -267,6 +281,10 @@ static_assert(Modulus<UINT64_C(0xffffffff00000001), 7>::multiply(
 static_assert(PAdic64SVE<Modulus<UINT64_C(0xfffffc6e80000001), 3>>::to_montgomery(1) ==
               UINT64_C(0x000003917fffffff));
 static_assert(bitreverse(1) == (std::uint64_t{1} << 63));
+static_assert(readme_blocked_six_step::kernel_type::get_inverse_factor() == 1);  // README: unscaled
+static_assert(test62::iterative_radix8::get_inverse_factor() == test62::m12);
+static_assert(test62::recursive_radix248::get_inverse_factor() == test62::m13);
+static_assert(test62::four_step::get_inverse_factor() == test62::m15);
 
 int main(int argc, char **argv) {
   if (argc > 1 && std::string{argv[1]} == "--compile-only-check") {
@@ -283,6 +301,7 @@ int main(int argc, char **argv) {
   ok &= check<test62::four_step, false>("recursive, SVE, four-step");
   ok &= check<test62::four_step, true>("recursive, SVE, four-step");
   ok &= check<big::kernel_type, false>("six-step 2^24 = 2^11 x 2^13");
+  ok &= check<big::kernel_type, true>("six-step 2^24 = 2^11 x 2^13");
   ok &= check_errors();
   ok &= check_transposition();
   ok &= check_kernel_concept();

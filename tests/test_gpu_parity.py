@@ -301,6 +301,9 @@ def test_forward_multiply_fused(eng, port, log2m, batch):
     s, o = dev(src), dev(operand)
     om = torch.empty_like(o)
     ntt.to_montgomery(om, o)
+    # every element: operand * 2^64 mod p (PAdic64SVE::to_montgomery, modmul/sve/p-adic-64.hpp:64-69)
+    want_m = np.array([(int(v) << 64) % P for v in operand[:4096]], dtype=np.uint64)
+    assert np.array_equal(host(om)[:want_m.size], want_m)
     assert int(host(om)[0]) == port.to_montgomery(int(operand[0]), P)
     back = torch.empty_like(o)
     ntt.from_montgomery(back, om)
@@ -354,6 +357,80 @@ def test_distinct_plans_on_concurrent_host_threads(eng, port):
     for i, (src, got, m, batch) in results.items():
         for b in range(batch):
             assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], P, G)), (i, b)
+
+
+def test_one_plan_shared_by_host_threads_with_host_pointers(eng, port):
+    """ADVICE r01 / include/sventt_hip.h "Threads and devices": host-pointer calls on ONE plan
+    stage through its single device buffer and must take turns, not corrupt each other.  The C++
+    facade shares one plan per kernel_type process-wide (plan_handle.hpp: shared_plan), so
+    independent callers of kernel_type::compute_forward do exactly this."""
+    import threading
+    m = 1 << 16
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    inputs = [port.fill_splitmix(m, 500 + i, P) for i in range(4)]
+    want = [port.forward(x, P, G) for x in inputs]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(12):
+                out = np.full(m, 0x5555555555555555, dtype=np.uint64)
+                ntt.compute_forward(out, inputs[i].copy())  # numpy arrays = host pointers
+                if not np.array_equal(out, want[i]):
+                    errors.append((i, "forward"))
+                    return
+                ntt.compute_inverse(out)
+                if not np.array_equal(out, inputs[i]):
+                    errors.append((i, "inverse"))
+                    return
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("log2m", [0, 1, 9, 13, 17, 24])
+def test_inverse_divisor(eng, port, log2m):
+    """sventt_plan_create_ex: the inverse multiplies by divisor^-1 (0 -> m, 1 -> unscaled).  The
+    reference's layers scale only where an inverse_factor says so (layer/sve/radix-two.hpp:208-235):
+    README-shaped kernels return m times the oracle's inverse."""
+    m = 1 << log2m
+    src = port.fill_splitmix(m, 77 + log2m, P)
+    want = port.inverse(src, P, G) if log2m <= 20 else None
+    if want is None:  # 2^24: check sampled elements against the scaled result of the default plan
+        base = eng.NTT(eng.Modulus(P, G), m, enable_forward=False)
+        t = dev(src)
+        base.compute_inverse(t)
+        want = host(t)
+    for divisor, factor in ((1, m % P), (0, 1), (12345, m * pow(12345, -1, P) % P)):
+        ntt = eng.NTT(eng.Modulus(P, G), m, enable_forward=False, inverse_divisor=divisor)
+        d = dev(src)
+        ntt.compute_inverse(d)
+        got = host(d)
+        idx = np.arange(m) if m <= (1 << 17) else np.random.default_rng(3).integers(0, m, 4096)
+        exp = np.array([int(want[i]) * factor % P for i in idx], dtype=np.uint64)
+        assert np.array_equal(got[idx], exp), (log2m, divisor)
+
+
+def test_device_pointers_flag(eng, port):
+    """SVENTT_DEVICE_POINTERS: same results without the pointer-kind queries."""
+    m = 1 << 12
+    src = port.fill_splitmix(m, 5, P)
+    ntt = eng.NTT(eng.Modulus(P, G), m, device_pointers=True)
+    s = dev(src)
+    d = torch.empty_like(s)
+    ntt.compute_forward(d, s)
+    assert np.array_equal(host(d), port.forward(src, P, G))
+    prod = torch.empty_like(s)
+    ntt.pointwise_multiply(prod, d, d)
+    ntt.compute_inverse(d)
+    assert np.array_equal(host(d), src)
+    assert ntt._lib.sventt_plan_device(ntt._h) == torch.cuda.current_device()
 
 
 def test_sharded_columns_entry_point_equals_chunked_path(eng):

@@ -214,6 +214,18 @@ def test_c_abi_argument_checking_needs_no_device():
     assert lib.sventt_plan_create(P, G, 1 << 10, 0, 1, 0, ctypes.byref(h)) == _lib.SVENTT_ERR_INVALID_ARGUMENT
     assert lib.sventt_sharded_plan_create(P, G, 1 << 20, 8, 3, 2, 3, ctypes.byref(h)) == _lib.SVENTT_ERR_INVALID_ARGUMENT
     assert lib.sventt_forward(None, None, None, None) == _lib.SVENTT_ERR_INVALID_ARGUMENT
+    # a composite modulus would give garbage tables (Fermat inverses): refused (Miller-Rabin)
+    composite = 0xFFFFFC6E80000001 - 2 ** 32  # odd, 2^10 | composite - 1, not prime
+    assert (composite - 1) % 1024 == 0 and pow(2, composite - 1, composite) != 1
+    assert lib.sventt_plan_create(composite, 3, 1 << 10, 0, 1, 3, ctypes.byref(h)) == _lib.SVENTT_ERR_INVALID_ARGUMENT
+    assert b"prime" in lib.sventt_last_error()
+    carmichael = 561  # 3 * 11 * 17: passes Fermat for every coprime base
+    assert lib.sventt_plan_create(carmichael, 2, 16, 0, 1, 3, ctypes.byref(h)) == _lib.SVENTT_ERR_INVALID_ARGUMENT
+    assert lib.sventt_plan_create(P, G, 1 << 10, 0, 1, 3 | 64, ctypes.byref(h)) == _lib.SVENTT_ERR_INVALID_ARGUMENT
+    assert b"flag" in lib.sventt_last_error()
+    # an inverse divisor that is 0 mod p has no inverse
+    assert lib.sventt_plan_create_ex(97, 5, 32, 0, 1, 3, 97 * 3, ctypes.byref(h)) == _lib.SVENTT_ERR_INVALID_ARGUMENT
+    assert lib.sventt_plan_device(None) == -1
     import torch
     if not torch.cuda.is_available():
         # valid arguments but no GPU: the library refuses instead of falling back
