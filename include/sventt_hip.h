@@ -48,7 +48,8 @@ enum {
   SVENTT_ERR_ALLOC = -2,            /* std::bad_alloc (vector.hpp:130-132) */
   SVENTT_ERR_HIP = -3,              /* a HIP runtime call failed */
   SVENTT_ERR_LOGIC = -4,            /* std::logic_error (wrapper.hpp:55) */
-  SVENTT_ERR_NO_DEVICE = -5         /* no gfx950 device visible */
+  SVENTT_ERR_NO_DEVICE = -5,        /* no gfx950 device visible */
+  SVENTT_ERR_COMM = -6              /* the exchange of a sharded transform failed (RCCL / transport) */
 };
 
 /* sventt_plan_create flags */
@@ -181,6 +182,49 @@ int sventt_run_pass_chunk(const sventt_plan *plan, int inverse, int pass_index,
                           uint64_t *dst, const uint64_t *src, uint32_t chunk,
                           uint32_t nchunks, int dst_compact, int src_compact,
                           void *stream);
+
+/*
+ * The whole sharded transform in one call, for C/C++ hosts (no torch): the column pass in
+ * `chunks` pieces, the all-to-all of each piece on an internal second stream as soon as the
+ * piece is written, the gather pass of a piece as soon as it has arrived, the remaining row
+ * passes.  `cols` / `rows` are this rank's plans from sventt_sharded_plan_create /
+ * sventt_sharded_rows_plan_create (same p, g, n, r_log2, rank, nranks).  All buffers hold
+ * n/nranks device words: forward reads the column slab `src` (left intact) and writes the row
+ * block `dst`; inverse reads the row block `src` (left intact) and writes the column slab
+ * `dst`; `work` and `recv` are scratch.  chunks >= 1 must divide
+ * sventt_plan_pass_tiles_per_block of both plans' pass 0 (1 always does; 4 is what the Python
+ * driver uses).  Work is enqueued on `stream` and on a plan-owned communication stream; the
+ * call returns without waiting.  Calls with the same `rows` plan take turns.
+ *
+ * sventt_sharded_forward / _inverse: the exchange is ncclSend / ncclRecv between
+ * ncclGroupStart / ncclGroupEnd on `nccl_comm` (an ncclComm_t of `nranks` ranks in which this
+ * process has the plans' rank); librccl is loaded on first use (dlopen), the library does not
+ * link it.  The *_transport variants take the exchange as a callback instead (MPI, a test
+ * loopback, another collective library):
+ *   all_to_all(ctx, send, recv, count, stream): piece h of `send` (count words each) goes to
+ *   rank h, piece s of `recv` comes from rank s; enqueue on `stream` (it may also block).
+ *   Return 0 on success.
+ */
+typedef struct sventt_transport {
+  void *ctx;
+  int (*all_to_all)(void *ctx, const uint64_t *send, uint64_t *recv, uint64_t count_per_peer,
+                    void *stream);
+} sventt_transport;
+
+int sventt_sharded_forward(const sventt_plan *cols, const sventt_plan *rows, void *nccl_comm,
+                           uint64_t *dst, const uint64_t *src, uint64_t *work, uint64_t *recv,
+                           uint32_t chunks, void *stream);
+int sventt_sharded_inverse(const sventt_plan *cols, const sventt_plan *rows, void *nccl_comm,
+                           uint64_t *dst, const uint64_t *src, uint64_t *work, uint64_t *recv,
+                           uint32_t chunks, void *stream);
+int sventt_sharded_forward_transport(const sventt_plan *cols, const sventt_plan *rows,
+                                     const sventt_transport *transport, uint64_t *dst,
+                                     const uint64_t *src, uint64_t *work, uint64_t *recv,
+                                     uint32_t chunks, void *stream);
+int sventt_sharded_inverse_transport(const sventt_plan *cols, const sventt_plan *rows,
+                                     const sventt_transport *transport, uint64_t *dst,
+                                     const uint64_t *src, uint64_t *work, uint64_t *recv,
+                                     uint32_t chunks, void *stream);
 
 /* Introspection (get_m(): wrapper.hpp:48; modulus_type: wrapper.hpp:32). */
 uint64_t sventt_plan_n(const sventt_plan *plan);

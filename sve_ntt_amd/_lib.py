@@ -18,6 +18,7 @@ SVENTT_ERR_ALLOC = -2
 SVENTT_ERR_HIP = -3
 SVENTT_ERR_LOGIC = -4
 SVENTT_ERR_NO_DEVICE = -5
+SVENTT_ERR_COMM = -6
 
 SVENTT_FORWARD = 1
 SVENTT_INVERSE = 2
@@ -45,6 +46,10 @@ SYMBOLS = {
     "sventt_sharded_rows_plan_create": (_int, [_u64, _u64, _u64, _u32, _int, _int, _u32,
                                                ctypes.POINTER(_vp)]),
     "sventt_sharded_columns": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "sventt_sharded_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "sventt_sharded_inverse": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "sventt_sharded_forward_transport": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "sventt_sharded_inverse_transport": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "sventt_plan_n": (_u64, [_vp]),
     "sventt_plan_batch": (_u64, [_vp]),
     "sventt_plan_modulus": (_u64, [_vp]),

@@ -2,6 +2,8 @@
 // and the C ABI declared in include/sventt_hip.h.  The pass list itself is built
 // by plan_core.h (host-only).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: librccl is dlopen'ed on first use, never linked
 
 #include <cstring>
 #include <mutex>
@@ -59,6 +61,10 @@ struct sventt_plan {
   mutable std::mutex staging_mutex;
   mutable u64 *staging = nullptr;
   mutable size_t staging_elems = 0;
+  // sventt_sharded_forward/inverse (rows plan): the communication stream and per-chunk events
+  mutable std::mutex shard_mutex;
+  mutable hipStream_t comm_stream = nullptr;
+  mutable std::vector<hipEvent_t> piece_ready, piece_arrived;
 };
 
 namespace {
@@ -257,6 +263,9 @@ void sventt_plan_destroy(sventt_plan *pl) {
       if (d.twist_hi) (void)hipFree(d.twist_hi);
     }
   if (pl->staging) (void)hipFree(pl->staging);
+  for (hipEvent_t e : pl->piece_ready) (void)hipEventDestroy(e);
+  for (hipEvent_t e : pl->piece_arrived) (void)hipEventDestroy(e);
+  if (pl->comm_stream) (void)hipStreamDestroy(pl->comm_stream);
   delete pl;
 }
 
@@ -333,6 +342,230 @@ int sventt_sharded_columns(const sventt_plan *pl, int inverse, uint64_t *dst, co
   if ((inverse ? pl->inv : pl->fwd).empty())
     return fail(SVENTT_ERR_LOGIC, "direction not enabled in this plan");
   return run_pass(pl, inverse != 0, 0, dst, src, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+// ---- the sharded transform as one call ------------------------------------------------
+namespace {
+
+int run_chunk(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const u64 *src, u32 chunk,
+              u32 nchunks, bool dst_compact, bool src_compact, hipStream_t stream) {
+  const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[index];
+  const DevicePass &d = (inverse ? pl->inv : pl->fwd)[index];
+  PassArgs a;
+  u32 grid = 0;
+  std::string err;
+  if (make_chunk_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi, chunk, nchunks,
+                      dst_compact, src_compact, a, grid, err))
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, err);
+  HIP_TRY(d.kernel->launch(a, grid, stream));
+  return SVENTT_OK;
+}
+
+int check_shard_pair(const sventt_plan *cols, const sventt_plan *rows, bool inverse, u32 chunks) {
+  if (!cols->host.sharded || cols->host.local_cols == 0)
+    return fail(SVENTT_ERR_LOGIC, "`cols` is not a sharded column plan");
+  if (!rows->host.sharded || rows->host.local_cols != 0 || rows->host.nranks < 2)
+    return fail(SVENTT_ERR_LOGIC, "`rows` is not a sharded rows plan");
+  if (cols->host.nranks != rows->host.nranks || cols->host.rank != rows->host.rank ||
+      cols->host.f.N != rows->host.f.N || cols->host.total != rows->host.total)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "the two plans do not describe the same rank of the same transform");
+  if ((inverse ? cols->inv : cols->fwd).empty() || (inverse ? rows->inv : rows->fwd).empty())
+    return fail(SVENTT_ERR_LOGIC, "direction not enabled in these plans");
+  const HostPass &cp = (inverse ? cols->host.inv : cols->host.fwd)[0];
+  const std::vector<HostPass> &rp = inverse ? rows->host.inv : rows->host.fwd;
+  const HostPass &xp = inverse ? rp.back() : rp.front();  // the pass next to the exchange
+  if (chunks == 0 || (cp.istride >> cp.f0) % chunks != 0 || (xp.istride >> xp.f0) % chunks != 0)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "chunks must divide the column tile counts of both plans");
+  if (cols->host.total % ((u64)chunks * (u64)cols->host.nranks) != 0)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "chunks do not divide the local data");
+  return SVENTT_OK;
+}
+
+int ensure_shard_ctx(const sventt_plan *rows, u32 chunks) {
+  if (!rows->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&rows->comm_stream, hipStreamNonBlocking));
+  while (rows->piece_ready.size() < chunks) {
+    hipEvent_t a = nullptr, b = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    rows->piece_ready.push_back(a);
+    HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    rows->piece_arrived.push_back(b);
+  }
+  return SVENTT_OK;
+}
+
+int sharded_transform(const sventt_plan *cols, const sventt_plan *rows, const sventt_transport *tr,
+                      bool inverse, u64 *dst, const u64 *src, u64 *work, u64 *recv, u32 chunks,
+                      void *stream_) {
+  if (!cols || !rows || !tr || !tr->all_to_all || !dst || !src || !work || !recv)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  if (dst == src || work == recv || work == dst || recv == dst || work == src || recv == src)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "dst, src, work and recv must be four distinct buffers");
+  int rc = check_shard_pair(cols, rows, inverse, chunks);
+  if (rc) return rc;
+  if ((rc = check_current_device(cols)) || (rc = check_current_device(rows))) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  std::lock_guard<std::mutex> lock(rows->shard_mutex);
+  if ((rc = ensure_shard_ctx(rows, chunks))) return rc;
+  hipStream_t comm = rows->comm_stream;
+  const u32 K = chunks;
+  const u64 piece = cols->host.total / K;               // words per chunk
+  const u64 per_peer = piece / (u64)cols->host.nranks;  // words per chunk and peer
+  const size_t rows_passes = (inverse ? rows->inv : rows->fwd).size();
+  auto exchange = [&](u32 k, u64 *out, const u64 *in) -> int {
+    // `in` is complete once the launches enqueued so far on `stream` have run
+    HIP_TRY(hipEventRecord(rows->piece_ready[k], stream));
+    HIP_TRY(hipStreamWaitEvent(comm, rows->piece_ready[k], 0));
+    if (tr->all_to_all(tr->ctx, in, out, per_peer, comm) != 0)
+      return fail(SVENTT_ERR_COMM, "the transport's all_to_all failed");
+    HIP_TRY(hipEventRecord(rows->piece_arrived[k], comm));
+    return SVENTT_OK;
+  };
+  if (!inverse) {
+    for (u32 k = 0; k < K; ++k) {
+      // chunk k of the column pass, written compactly: row block h of the piece is what rank h needs
+      if ((rc = run_chunk(cols, false, 0, work + k * piece, src, k, K, true, false, stream))) return rc;
+      if ((rc = exchange(k, recv + k * piece, work + k * piece))) return rc;
+    }
+    for (u32 k = 0; k < K; ++k) {
+      HIP_TRY(hipStreamWaitEvent(stream, rows->piece_arrived[k], 0));
+      // first pass of the row transform: reads the received pieces in place of a transposition
+      if ((rc = run_chunk(rows, false, 0, dst, recv + k * piece, k, K, false, true, stream))) return rc;
+    }
+    for (size_t i = 1; i < rows_passes; ++i)
+      if ((rc = run_pass(rows, false, i, dst, dst, stream))) return rc;
+  } else {
+    // rows passes but the last run on `dst` (free until the column pass writes it; every read of it
+    // is enqueued before the first such write); the last one scatters chunk k into piece layout
+    const u64 *cur = src;
+    for (size_t i = 0; i + 1 < rows_passes; ++i) {
+      if ((rc = run_pass(rows, true, i, dst, cur, stream))) return rc;
+      cur = dst;
+    }
+    for (u32 k = 0; k < K; ++k) {
+      if ((rc = run_chunk(rows, true, rows_passes - 1, work + k * piece, cur, k, K, true, false, stream)))
+        return rc;
+      if ((rc = exchange(k, recv + k * piece, work + k * piece))) return rc;
+    }
+    for (u32 k = 0; k < K; ++k) {
+      HIP_TRY(hipStreamWaitEvent(stream, rows->piece_arrived[k], 0));
+      if ((rc = run_chunk(cols, true, 0, dst, recv + k * piece, k, K, false, true, stream))) return rc;
+    }
+  }
+  // the next call may reuse work/recv on `stream`: order it after this call's exchanges
+  return SVENTT_OK;
+}
+
+// RCCL, loaded on first use so that single-GPU users do not need the library
+struct Rccl {
+  void *handle = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+const Rccl &rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (x.handle) break;
+    }
+    if (!x.handle) {
+      x.error = std::string("cannot load librccl: ") + dlerror();
+      return x;
+    }
+    auto sym = [&](const char *n) {
+      void *p = dlsym(x.handle, n);
+      if (!p && x.error.empty()) x.error = std::string("librccl lacks ") + n;
+      return p;
+    };
+    x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+    x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+    x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
+    x.Recv = reinterpret_cast<decltype(x.Recv)>(sym("ncclRecv"));
+    x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+    x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(sym("ncclCommUserRank"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+    return x;
+  }();
+  return r;
+}
+
+struct RcclCtx {
+  ncclComm_t comm;
+  int nranks;
+};
+
+int rccl_all_to_all(void *ctx_, const uint64_t *send, uint64_t *recv, uint64_t count, void *stream_) {
+  const RcclCtx *ctx = static_cast<const RcclCtx *>(ctx_);
+  const Rccl &r = rccl();
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ncclResult_t e = r.GroupStart();
+  for (int peer = 0; peer < ctx->nranks && e == ncclSuccess; ++peer) {
+    e = r.Send(send + (size_t)peer * count, count, ncclUint64, peer, ctx->comm, stream);
+    if (e == ncclSuccess) e = r.Recv(recv + (size_t)peer * count, count, ncclUint64, peer, ctx->comm, stream);
+  }
+  const ncclResult_t e2 = r.GroupEnd();
+  if (e == ncclSuccess) e = e2;
+  if (e != ncclSuccess) {
+    g_last_error = std::string("RCCL: ") + r.GetErrorString(e);
+    return 1;
+  }
+  return 0;
+}
+
+int sharded_rccl(const sventt_plan *cols, const sventt_plan *rows, void *nccl_comm, bool inverse,
+                 u64 *dst, const u64 *src, u64 *work, u64 *recv, u32 chunks, void *stream) {
+  if (!cols || !rows || !nccl_comm) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
+  const Rccl &r = rccl();
+  if (!r.error.empty()) return fail(SVENTT_ERR_COMM, r.error);
+  RcclCtx ctx{static_cast<ncclComm_t>(nccl_comm), 0};
+  int rank = -1;
+  if (r.CommCount(ctx.comm, &ctx.nranks) != ncclSuccess || r.CommUserRank(ctx.comm, &rank) != ncclSuccess)
+    return fail(SVENTT_ERR_COMM, "cannot query the communicator");
+  if (ctx.nranks != rows->host.nranks || rank != rows->host.rank)
+    return fail(SVENTT_ERR_INVALID_ARGUMENT, "the communicator's size/rank differ from the plans'");
+  const sventt_transport tr{&ctx, &rccl_all_to_all};
+  const int rc = sharded_transform(cols, rows, &tr, inverse, dst, src, work, recv, chunks, stream);
+  if (rc == SVENTT_ERR_COMM && g_last_error.rfind("RCCL", 0) != 0) g_last_error = "RCCL exchange failed";
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sventt_sharded_forward_transport(const sventt_plan *cols, const sventt_plan *rows,
+                                     const sventt_transport *transport, uint64_t *dst,
+                                     const uint64_t *src, uint64_t *work, uint64_t *recv,
+                                     uint32_t chunks, void *stream) {
+  return sharded_transform(cols, rows, transport, false, dst, src, work, recv, chunks, stream);
+}
+
+int sventt_sharded_inverse_transport(const sventt_plan *cols, const sventt_plan *rows,
+                                     const sventt_transport *transport, uint64_t *dst,
+                                     const uint64_t *src, uint64_t *work, uint64_t *recv,
+                                     uint32_t chunks, void *stream) {
+  return sharded_transform(cols, rows, transport, true, dst, src, work, recv, chunks, stream);
+}
+
+int sventt_sharded_forward(const sventt_plan *cols, const sventt_plan *rows, void *nccl_comm,
+                           uint64_t *dst, const uint64_t *src, uint64_t *work, uint64_t *recv,
+                           uint32_t chunks, void *stream) {
+  return sharded_rccl(cols, rows, nccl_comm, false, dst, src, work, recv, chunks, stream);
+}
+
+int sventt_sharded_inverse(const sventt_plan *cols, const sventt_plan *rows, void *nccl_comm,
+                           uint64_t *dst, const uint64_t *src, uint64_t *work, uint64_t *recv,
+                           uint32_t chunks, void *stream) {
+  return sharded_rccl(cols, rows, nccl_comm, true, dst, src, work, recv, chunks, stream);
 }
 
 uint64_t sventt_plan_n(const sventt_plan *pl) { return pl ? pl->host.n : 0; }

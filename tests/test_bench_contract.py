@@ -31,15 +31,42 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 1e9 < out["value"] < 1e12
     assert abs(out["value"] - (1 << 24) / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
     roof = out["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "dominant_kernel",
+                "dominant_kernel_ms", "dominant_kernel_frac", "transform_device_ms", "all_phases_ms"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.02 < roof["frac"] < 1.0
+    # `frac` is the transform-level figure the target is stated on (16 B per element per TRANSFORM
+    # over the sum of the kernel times); the slowest kernel's per-launch figure is secondary
+    want = 16 * (1 << 24) / (roof["transform_device_ms"] * 1e-3) / 8.0e12
+    assert abs(roof["frac"] - want) / want < 1e-6
+    assert roof["frac"] < roof["dominant_kernel_frac"] < 1.0
+    assert abs(sum(ms for _n, ms in roof["all_phases_ms"]) - roof["transform_device_ms"]) < 1e-6
     assert roof["traffic"] is None or roof["traffic"] >= roof["algorithmic_bytes_per_launch"]
+    if "valu" in out:  # present when profiles/valu.json is committed
+        for k, v in out["valu"]["kernels"].items():
+            assert v["instructions_per_element"] > 50 and v["cycles_per_instruction_per_simd"] > 1.5, k
     cpu = out["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,elements", [("cfg2", 1 << 17), ("cfg4", 1 << 28), ("roundtrip", 1 << 24)])
+def test_bench_other_configs_share_the_schema(config, elements):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "8",
+                        "--warmup", "2", "--prewarm", "20", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    for key, typ in REQUIRED.items():
+        if key != "cpu_baseline":
+            assert key in out and isinstance(out[key], typ), key
+    assert out["config"]["name"] == config and out["config"]["elements_per_step"] == elements
+    per_step = elements * (2 if config == "roundtrip" else 1)
+    assert abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+    assert 0.0 < out["roofline"]["frac"] < 1.0
 
 
 @pytest.mark.gpu

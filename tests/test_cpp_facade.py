@@ -64,6 +64,42 @@ def test_device_pointer_convolution_in_cpp():
     assert "ALL OK" in r.stdout and "MISMATCH" not in r.stdout
 
 
+SHARD_EXE = os.path.join(ROOT, "tests", "cpp", "sharded_driver")
+
+
+def _build_sharded_harness():
+    import oracle
+    oracle.build()
+    from sve_ntt_amd import build as hip_build
+    hip_build.build()
+    cmd = ["g++", "-std=c++20", "-O2", "-Wall", "-Wextra", "-pthread", "-I" + os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(ROOT, "tests", "cpp", "sharded_driver.cpp"),
+           "-L" + os.path.join(ROOT, "sve_ntt_amd"), "-lsventt_hip",
+           "-L" + os.path.join(ROOT, "oracle"), "-lntt_oracle", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "sve_ntt_amd"),
+           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath,/opt/rocm/lib", "-o", SHARD_EXE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_sharded_c_driver_compiles_and_links():
+    _build_sharded_harness()
+    r = subprocess.run([SHARD_EXE, "--compile-only-check"], capture_output=True, text=True)
+    assert r.returncode == 0 and "compiled and linked" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_c_driver_with_loopback_transport():
+    """sventt_sharded_forward/inverse_transport from C++: 2 and 4 ranks as host threads on the
+    one GPU, exchange through a loopback transport, every rank's output == its oracle slice."""
+    _build_sharded_harness()
+    r = subprocess.run([SHARD_EXE], capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ALL OK" in r.stdout and "MISMATCH" not in r.stdout
+
+
 def test_facade_compiles_and_links():
     _build()
     r = subprocess.run([EXE, "--compile-only-check"], capture_output=True, text=True)

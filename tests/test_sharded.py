@@ -44,6 +44,24 @@ def test_sharded_gloo_host_replay(world, log2n, r_log2, chunks):
     assert "forward=OK" in out and "inverse=OK" in out, out
 
 
+@pytest.mark.parametrize("world,log2n,r_log2,chunks", [(2, 16, 6, 4), (8, 20, 8, 2)])
+def test_sharded_gloo_closed_form_check(world, log2n, r_log2, chunks):
+    """The verification mode for sizes no oracle run fits (BASELINE config #5, N = 2^30 on 8
+    GPUs): iota input, sampled outputs against X[k] = m / (omega^k - 1), inverse == input.
+    Rehearsed here on the host replay with 2 and 8 ranks."""
+    out = _run(world, {"ENGINE": "sim", "LOG2N": str(log2n), "R_LOG2": str(r_log2),
+                       "CHUNKS": str(chunks), "CHECK": "closed", "SAMPLES": "256"})
+    assert "forward=OK" in out and "inverse=OK" in out and "closed-form" in out, out
+
+
+@pytest.mark.gpu
+def test_sharded_two_ranks_closed_form_on_one_gpu():
+    """The same mode through the HIP kernels at 2^27 (two ranks share the card; host-bounced
+    exchange): what `LOG2N=30 CHECK=closed` runs on an 8-GPU node."""
+    out = _run(2, {"ENGINE": "hip", "LOG2N": "27", "R_LOG2": "11", "CHECK": "closed"}, timeout=600)
+    assert "forward=OK" in out and "inverse=OK" in out and "closed-form" in out, out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("log2n,r_log2", [(20, 8), (25, 11)])
 def test_sharded_two_ranks_on_one_gpu(log2n, r_log2):
