@@ -301,7 +301,11 @@ struct TileNTT {
         const u64 *p0 = a.src + saddr(a, t, I0[g]);
 #pragma unroll
         for (int v = 0; v < R; ++v)
+#if defined(SVENTT_STUB_HBM)  // analysis builds only (tools/build_variant.sh stub): no HBM access
+          x[g * R + v] = (u64)(uintptr_t)(p0 + (u64)v * vstride) >> 1;
+#else
           x[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
+#endif
       } else {
         const u32 P0 = lds_phys(I0[g]);
 #pragma unroll
@@ -331,7 +335,11 @@ struct TileNTT {
         u64 *p0 = a.dst + gaddr(a, t, I0[g]);
 #pragma unroll
         for (int v = 0; v < R; ++v)
+#if defined(SVENTT_STUB_HBM)
+          if (x[g * R + v] == 0x123456789abcdefull) p0[(u64)v * vstride] = x[g * R + v];
+#else
           if (in_range(a, t, I0[g] | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
+#endif
       }
     } else {
 #pragma unroll
