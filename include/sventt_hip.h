@@ -57,9 +57,16 @@ enum {
   SVENTT_FORWARD = 1u, /* NTT(enable_forward=true, ...)   wrapper.hpp:34 */
   SVENTT_INVERSE = 2u, /* NTT(..., enable_inverse=true)   wrapper.hpp:34 */
   SVENTT_BOTH = 3u,
-  SVENTT_DEVICE_POINTERS = 4u /* every dst/src/operand ever passed with this plan is memory of the
-                                 plan's device: the calls skip hipPointerGetAttributes (two driver
-                                 queries per transform, a visible share of a 10 us small transform) */
+  SVENTT_DEVICE_POINTERS = 4u, /* every dst/src/operand ever passed with this plan is memory of the
+                                  plan's device: the calls skip hipPointerGetAttributes (two driver
+                                  queries per transform, a visible share of a 10 us small transform) */
+  /* Arithmetic back end of the kernels (results are the same canonical residues with every one):
+   * default = Montgomery multiplication (PAdic64SVE, modmul/sve/p-adic-64.hpp of the reference),
+   * except for p = 2^64 - 2^32 + 1, which gets kernels with that prime's folding reduction. */
+  SVENTT_GENERIC_ARITHMETIC = 8u, /* Montgomery kernels for every modulus */
+  SVENTT_FIXED_POINT = 16u        /* FixedPoint64SVE / FixedPoint64Scalar (modmul/sve/fixed-point-64.hpp:
+                                     33-68): Shoup multiplication c = a*w - hi64(a*w')*N with w' stored
+                                     beside every twiddle; needs p < 2^63 */
 };
 
 /*

@@ -110,13 +110,15 @@ class NTT:
     1 = unscaled (what the reference's layers compute when none carries an
     ``inverse_factor``, layer/sve/radix-two.hpp:208-235).  ``device_pointers``:
     promise that every buffer is memory of the plan's device (skips the
-    pointer-kind queries of each call).
+    pointer-kind queries of each call).  ``arithmetic``: "auto", "generic" (the
+    reference's PAdic64 modmul for every modulus) or "fixed_point" (its FixedPoint64
+    modmul, modmul/sve/fixed-point-64.hpp) -- results are identical, speed is not.
     """
 
     def __init__(self, modulus: Modulus, m: int, n0_log2: int = 0, batch: int = 1,
                  enable_forward: bool = True, enable_inverse: bool = True,
                  allocate_huge_pages: bool = True, inverse_divisor: int = 0,
-                 device_pointers: bool = False):
+                 device_pointers: bool = False, arithmetic: str = "auto"):
         del allocate_huge_pages  # accepted for signature parity; device tables need no huge pages
         self._lib = _lib.load()
         self.modulus_type = modulus
@@ -124,7 +126,11 @@ class NTT:
         self._batch = batch
         flags = (_lib.SVENTT_FORWARD if enable_forward else 0) | (
             _lib.SVENTT_INVERSE if enable_inverse else 0) | (
-            _lib.SVENTT_DEVICE_POINTERS if device_pointers else 0)
+            _lib.SVENTT_DEVICE_POINTERS if device_pointers else 0) | {
+                "auto": 0,  # Montgomery; the Goldilocks prime gets its own folding reduction
+                "generic": _lib.SVENTT_GENERIC_ARITHMETIC,  # PAdic64 (Montgomery) for every modulus
+                "fixed_point": _lib.SVENTT_FIXED_POINT,  # FixedPoint64 (Shoup), modulus < 2^63
+            }[arithmetic]
         h = ctypes.c_void_p()
         _lib.check(self._lib.sventt_plan_create_ex(modulus.modulus, modulus.generator, m, n0_log2,
                                                    batch, flags, inverse_divisor, ctypes.byref(h)))

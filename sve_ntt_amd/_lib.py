@@ -24,6 +24,8 @@ SVENTT_FORWARD = 1
 SVENTT_INVERSE = 2
 SVENTT_BOTH = 3
 SVENTT_DEVICE_POINTERS = 4
+SVENTT_GENERIC_ARITHMETIC = 8
+SVENTT_FIXED_POINT = 16
 
 # name -> (restype, argtypes); must list every symbol include/sventt_hip.h declares
 _u64 = ctypes.c_uint64

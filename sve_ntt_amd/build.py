@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsventt_hip.so")
-SOURCES = ["kernels.hip", "plan.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
+SOURCES = ["kernels.hip", "kernels_gold.hip", "kernels_shoup.hip", "plan.hip"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [
     os.path.join(ROOT, "include", "sventt_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",

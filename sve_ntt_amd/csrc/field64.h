@@ -23,6 +23,8 @@
 
 #include <stdint.h>
 
+#include <vector>
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define F64_HD __host__ __device__ __forceinline__
@@ -148,6 +150,74 @@ F64_HD void butterfly_inv(u64 &x0, u64 &x1, u64 w, const Field &f) {
 
 F64_HD void butterfly_inv(u64 &x0, u64 &x1, const Field &f) { butterfly_fwd(x0, x1, f); }
 
+// ---- arithmetic back ends -----------------------------------------------------------
+// The tile kernels are instantiated per back end (TileNTT's ARITH parameter); every one of them
+// takes canonical residues in and gives canonical residues out, so passes of different back
+// ends can follow each other and every result equals the oracle's bit for bit.
+//   ARITH_MONT   any odd prime < 2^64: Montgomery product above; twiddles as w * 2^64 mod N.
+//                (PAdic64SVE / PAdic64Scalar of the reference, modmul/sve/p-adic-64.hpp)
+//   ARITH_GOLD   N = 2^64 - 2^32 + 1 only: 2^64 = 2^32 - 1 and 2^96 = -1 (mod N), so a 128-bit
+//                product folds with one subtraction and one 32 x 32 multiply-add; twiddles plain.
+//                (the "Goldilocks reduction" fast path of SURVEY.md 8f; the reference has none)
+//   ARITH_SHOUP  N < 2^63: c = a*w - floor(a*w'/2^64)*N with the precomputed w' = floor(w*2^64/N)
+//                stored beside every twiddle (FixedPoint64SVE / FixedPoint64Scalar of the
+//                reference, modmul/sve/fixed-point-64.hpp:60-68); twiddles plain, two words each.
+enum : int { ARITH_MONT = 0, ARITH_GOLD = 1, ARITH_SHOUP = 2, ARITH_COUNT = 3 };
+
+constexpr u64 GOLDILOCKS_N = 0xffffffff00000001ull;
+constexpr u64 GOLDILOCKS_EPS = 0xffffffffull;  // 2^64 mod N = 2^32 - 1
+
+// a * w mod N for N = 2^64 - 2^32 + 1, canonical; w < N, a any 64-bit value.
+F64_HD u64 gold_mul(u64 a, u64 w, const Field &f) {
+  u64 hi, lo;
+  mul64x64(a, w, hi, lo);
+  const u32 t2 = (u32)hi, t3 = (u32)(hi >> 32);
+  u64 r;
+  const bool borrow = sub64_borrow(lo, (u64)t3, r);       // t3 * 2^96 = -t3
+  r += borrow ? f.N : 0;                                   // the wrap added 2^64 = eps: take it back (-eps = +N mod 2^64)
+  u64 r2;
+  const bool carry = add64_carry(r, mad32(t2, (u32)GOLDILOCKS_EPS, 0), r2);  // t2 * 2^64 = t2 * eps
+  r2 += carry ? GOLDILOCKS_EPS : 0;                        // cannot wrap again: t2*eps <= 2^64 - 2^33 + 1
+  return r2 + (r2 >= f.N ? GOLDILOCKS_EPS : 0);            // - N
+}
+
+// FixedPoint64*::multiply (modmul/scalar/fixed-point-64.hpp:47-55) followed by the one
+// conditional subtraction that makes the result canonical; w < N < 2^63, a any 64-bit value.
+F64_HD u64 shoup_mul(u64 a, u64 w, u64 wp, const Field &f) {
+  const u64 q = mulhi64(a, wp);
+  const u64 c = a * w - q * f.N;  // in [0, 2N)
+  return c - (c >= f.N ? f.N : 0);
+}
+
+// One twiddle of a stage / twist table is TW_WORDS consecutive 64-bit words.
+template <int ARITH> struct Arith;
+template <> struct Arith<ARITH_MONT> {
+  static constexpr int TW_WORDS = 1;
+  F64_HD static u64 mul(u64 a, const u64 *tw, const Field &f) { return montmul(a, tw[0], f); }
+};
+template <> struct Arith<ARITH_GOLD> {
+  static constexpr int TW_WORDS = 1;
+  F64_HD static u64 mul(u64 a, const u64 *tw, const Field &f) { return gold_mul(a, tw[0], f); }
+};
+template <> struct Arith<ARITH_SHOUP> {
+  static constexpr int TW_WORDS = 2;
+  F64_HD static u64 mul(u64 a, const u64 *tw, const Field &f) { return shoup_mul(a, tw[0], tw[1], f); }
+};
+
+// butterflies with the twiddle taken from a table entry
+template <int ARITH> F64_HD void butterfly_fwd_tw(u64 &x0, u64 &x1, const u64 *tw, const Field &f) {
+  const u64 s = addmod(x0, x1, f);
+  const u64 d = submod(x0, x1, f);
+  x0 = s;
+  x1 = Arith<ARITH>::mul(d, tw, f);
+}
+template <int ARITH> F64_HD void butterfly_inv_tw(u64 &x0, u64 &x1, const u64 *tw, const Field &f) {
+  const u64 t = Arith<ARITH>::mul(x1, tw, f);
+  const u64 s = addmod(x0, t, f);
+  x1 = submod(x0, t, f);
+  x0 = s;
+}
+
 // ---- host-side field helpers (plan construction only) ----------------------
 typedef unsigned __int128 u128;
 inline u64 h_mulmod(u64 a, u64 b, u64 N) { return (u64)(((u128)a * b) % N); }
@@ -168,5 +238,18 @@ inline u64 h_montgomery_inverse(u64 N) {
   return x;
 }
 inline u64 h_to_montgomery(u64 a, u64 N) { return (u64)((((u128)a) << 64) % N); }
+// floor(w * 2^64 / N): FixedPoint64*::precompute with its correction (fixed-point-64.hpp:25-44)
+inline u64 h_shoup_precompute(u64 w, u64 N) { return (u64)((((u128)w) << 64) / N); }
+// appends the table form of the plain residue `a` for a back end
+inline void h_push_twiddle(std::vector<u64> &t, int arith, u64 a, u64 N);
+
+inline void h_push_twiddle(std::vector<u64> &t, int arith, u64 a, u64 N) {
+  if (arith == ARITH_MONT) {
+    t.push_back(h_to_montgomery(a, N));
+  } else {
+    t.push_back(a);
+    if (arith == ARITH_SHOUP) t.push_back(h_shoup_precompute(a, N));
+  }
+}
 
 }  // namespace sventt_hip

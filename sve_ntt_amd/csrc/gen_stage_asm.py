@@ -74,9 +74,10 @@ def mont(S, al, ah, w0, w1):
     ]
 
 
-def fix_if(S_mask, reg):
-    """+N on the lanes whose bit is set in the SGPR pair"""
-    return ('fix', 's_and_b64 exec, %%[save], %s' % S_mask, 'v_lshl_add_u64 %s, %s, 0, %%[N]' % (pair(reg), pair(reg)))
+def fix_if(S_mask, reg, addend='%[N]'):
+    """+N (or another SGPR-pair addend) on the lanes whose bit is set in the SGPR pair"""
+    return ('fix', 's_and_b64 exec, %%[save], %s' % S_mask,
+            'v_lshl_add_u64 %s, %s, 0, %s' % (pair(reg), pair(reg), addend))
 
 
 def fix_ifnot(S_mask, reg):
@@ -94,8 +95,74 @@ def mont_result(S, dl):
     return sub_into(S, dl, S.h, S.h + 1, S.m2, S.m2 + 1) + [fix_if(S.sb, dl)]
 
 
-def bf_fwd(S, x, y, w0, w1):
-    """(x, y) <- (x + y, (x - y) * w)      field64.h: butterfly_fwd"""
+ARITHS = ('ARITH_MONT', 'ARITH_GOLD', 'ARITH_SHOUP')
+
+
+def product128(S, al, ah, w0, w1):
+    """m0.lo = t0, m2.lo = t1, h = (t2, t3) of a * w"""
+    m0, m1, m2, h, z = S.m0, S.m1, S.m2, S.h, S.z
+    return [
+        'v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(m0), al, w0),
+        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m1), al, w1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m1 + 1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(h), ah, w1, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, w0, pair(z)),
+        'v_mov_b32 v%d, v%d' % (z, m2 + 1),
+        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),
+    ]
+
+
+def gold_mul(S, al, ah, w0, w1, dst):
+    """v[dst:dst+1] = a * w mod 2^64 - 2^32 + 1, canonical (field64.h: gold_mul).  negN = eps."""
+    m0, m2, h = S.m0, S.m2, S.h
+    return (product128(S, al, ah, w0, w1) +
+            ['v_mov_b32 v%d, v%d' % (m0 + 1, m2),                                  # lo = {t0, t1}
+             'v_sub_co_u32 v%d, %s, v%d, v%d' % (dst, S.sb, m0, h + 1),             # lo - t3
+             'v_subb_co_u32 v%d, %s, v%d, 0, %s' % (dst + 1, S.sb, m0 + 1, S.sb),
+             fix_if(S.sb, dst),                                                     # wrapped: -eps = +N
+             'v_mad_u64_u32 %s, %s, v%d, %%[nn0], %s' % (pair(dst), S.sc, h, pair(dst)),  # + t2 * eps
+             fix_if(S.sc, dst, '%[negN]'),                                          # wrapped: +eps
+             'v_cmp_ge_u64 %s, %s, %%[N]' % (S.sb, pair(dst)),
+             fix_if(S.sb, dst, '%[negN]')])                                         # >= N: -N = +eps
+
+
+def shoup_mul(S, al, ah, w0, w1, p0, p1, dst):
+    """v[dst:dst+1] = a*w - hi64(a*w')*N, then -N if >= N (field64.h: shoup_mul); dst must not
+    hold a.  negN = 2^64 - N as (nn0, nn1)."""
+    m1, m2, h, z = S.m1, S.m2, S.h, S.z
+    return ['v_mul_hi_u32 v%d, %s, %s' % (z, al, p0),
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m1), al, p1, pair(z)),
+            'v_mov_b32 v%d, v%d' % (z, m1 + 1),
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(h), ah, p1, pair(z)),
+            'v_mov_b32 v%d, v%d' % (z, m1),
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, p0, pair(z)),
+            'v_mov_b32 v%d, v%d' % (z, m2 + 1),
+            'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),           # q = hi64(a * w')
+            'v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(dst), al, w0),
+            'v_mad_u64_u32 %s, vcc, v%d, %%[nn0], %s' % (pair(dst), h, pair(dst)),  # + q0 * negN0
+            'v_mov_b32 v%d, v%d' % (m2, dst + 1),                                   # high word: only m2.lo counts
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), al, w1, pair(m2)),
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, w0, pair(m2)),
+            'v_mad_u64_u32 %s, vcc, v%d, %%[nn1], %s' % (pair(m2), h, pair(m2)),
+            'v_mad_u64_u32 %s, vcc, v%d, %%[nn0], %s' % (pair(m2), h + 1, pair(m2)),
+            'v_mov_b32 v%d, v%d' % (dst + 1, m2),
+            'v_cmp_ge_u64 %s, %s, %%[N]' % (S.sb, pair(dst)),
+            fix_if(S.sb, dst, '%[negN]')]
+
+
+def mulmod(arith, S, al, ah, W, dst):
+    """v[dst:dst+1] = a * w in the back end's domain, canonical.  W = (w0, w1[, p0, p1])."""
+    if arith == 'ARITH_MONT':
+        return mont(S, al, ah, W[0], W[1]) + mont_result(S, dst)
+    if arith == 'ARITH_GOLD':
+        return gold_mul(S, al, ah, W[0], W[1], dst)
+    return shoup_mul(S, al, ah, W[0], W[1], W[2], W[3], dst)
+
+
+def bf_fwd_a(arith, S, x, y, W):
+    """(x, y) <- (x + y, (x - y) * w)"""
     e = S.m2
     return (zero_ext_init(S) +
             ['v_sub_co_u32 v%d, %s, v%d, v%d' % (S.d, S.sb, x, y),
@@ -105,7 +172,29 @@ def bf_fwd(S, x, y, w0, w1):
              fix_if(S.sb, S.d),
              'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (x + 1, S.sc, x + 1, e + 1, S.sc),
              fix_ifnot(S.sc, x)] +
-            mont(S, 'v%d' % S.d, 'v%d' % (S.d + 1), w0, w1) + mont_result(S, y))
+            mulmod(arith, S, 'v%d' % S.d, 'v%d' % (S.d + 1), W, y))
+
+
+def bf_inv_a(arith, S, x, y, W):
+    """(x, y) <- (x + y*w, x - y*w)"""
+    e = S.m0
+    return (zero_ext_init(S) + mulmod(arith, S, 'v%d' % y, 'v%d' % (y + 1), W, S.d) +
+            ['v_lshl_add_u64 %s, %s, 0, %%[negN]' % (pair(e), pair(S.d)),
+             'v_sub_co_u32 v%d, %s, v%d, v%d' % (y, S.sb, x, S.d),
+             'v_add_co_u32 v%d, %s, v%d, v%d' % (x, S.sc, x, e),
+             'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (y + 1, S.sb, x + 1, S.d + 1, S.sb),
+             'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (x + 1, S.sc, x + 1, e + 1, S.sc),
+             fix_if(S.sb, y),
+             fix_ifnot(S.sc, x)])
+
+
+def twist_a(arith, S, x, H, L):
+    """x <- x * hi * lo;  H, L = (lo word, hi word[, companion lo, companion hi]) operand texts"""
+    xr = ('v%d' % x, 'v%d' % (x + 1))
+    dr = ('v%d' % S.d, 'v%d' % (S.d + 1))
+    if arith == 'ARITH_SHOUP':
+        return (zero_ext_init(S) + mulmod(arith, S, xr[0], xr[1], H, S.d) + mulmod(arith, S, dr[0], dr[1], L, x))
+    return (zero_ext_init(S) + mulmod(arith, S, H[0], H[1], L, S.d) + mulmod(arith, S, xr[0], xr[1], dr, x))
 
 
 def bf_plain(S, x, y):
@@ -120,28 +209,10 @@ def bf_plain(S, x, y):
             fix_ifnot(S.sc, x)]
 
 
-def bf_inv(S, x, y, w0, w1):
-    """(x, y) <- (x + y*w, x - y*w)        field64.h: butterfly_inv"""
-    e = S.m0
-    return (zero_ext_init(S) + mont(S, 'v%d' % y, 'v%d' % (y + 1), w0, w1) + mont_result(S, S.d) +
-            ['v_lshl_add_u64 %s, %s, 0, %%[negN]' % (pair(e), pair(S.d)),
-             'v_sub_co_u32 v%d, %s, v%d, v%d' % (y, S.sb, x, S.d),
-             'v_add_co_u32 v%d, %s, v%d, v%d' % (x, S.sc, x, e),
-             'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (y + 1, S.sb, x + 1, S.d + 1, S.sb),
-             'v_addc_co_u32 v%d, %s, v%d, v%d, %s' % (x + 1, S.sc, x + 1, e + 1, S.sc),
-             fix_if(S.sb, y),
-             fix_ifnot(S.sc, x)])
-
-
 def mul_inplace(S, x, w0, w1):
     """x <- x * w"""
     return zero_ext_init(S) + mont(S, 'v%d' % x, 'v%d' % (x + 1), w0, w1) + mont_result(S, x)
 
-
-def mul_composed(S, x, hi0, hi1, lo0, lo1):
-    """x <- x * (hi * lo)                  tile_ntt.h: twist_lookup + montmul"""
-    return (zero_ext_init(S) + mont(S, hi0, hi1, lo0, lo1) + mont_result(S, S.d) +
-            mont(S, 'v%d' % x, 'v%d' % (x + 1), 'v%d' % S.d, 'v%d' % (S.d + 1)) + mont_result(S, x))
 
 
 # ---- scheduling -------------------------------------------------------------------------------
@@ -175,6 +246,11 @@ def sgpr_written(ins):
     op = ins.split()[0]
     if op in ('v_sub_co_u32', 'v_subb_co_u32', 'v_add_co_u32', 'v_addc_co_u32'):
         return ins.split(',')[1].strip()
+    if op == 'v_mad_u64_u32':  # carry-out: "v[a:b], s[c:d], ..." -- the first comma is inside v[..]
+        sdst = ins.split('],', 1)[1].split(',')[0].strip()
+        return sdst if sdst.startswith('s[') else None
+    if op == 'v_cmp_ge_u64':
+        return ins.split()[1].rstrip(',')
     return None
 
 
@@ -203,8 +279,11 @@ def hazards(seq):
 
 
 # ---- C++ wrappers -------------------------------------------------------------------------------
-CONSTS = ['[N] "s"(c.N)', '[negN] "s"(c.negN)', '[n0] "s"(c.n0)', '[n1] "s"(c.n1)', '[ni0] "s"(c.ni0)',
-          '[ni1] "s"(c.ni1)', '[save] "s"(c.save)']
+CONSTS = {
+    'N': '[N] "s"(c.N)', 'negN': '[negN] "s"(c.negN)', 'n0': '[n0] "s"(c.n0)', 'n1': '[n1] "s"(c.n1)',
+    'ni0': '[ni0] "s"(c.ni0)', 'ni1': '[ni1] "s"(c.ni1)', 'save': '[save] "s"(c.save)',
+    'nn0': '[nn0] "s"(c.nn0)', 'nn1': '[nn1] "s"(c.nn1)',
+}
 
 
 def clobbers(W):
@@ -217,13 +296,15 @@ def clobbers(W):
 def asm_stmt(streams, data_regs, inputs):
     body = interleave(streams)
     text = ''.join('        "%s\\n\\t"\n' % l for l in body)
+    used = [k for k in CONSTS if any('%%[%s]' % k in l for l in body)]
     outs = ', '.join('"+{v[%d:%d]}"(x[%d])' % (2 * i, 2 * i + 1, i) for i in data_regs)
     return ('    asm volatile(\n%s        : %s\n        : %s\n        : %s);\n'
-            % (text, outs, ', '.join(inputs + CONSTS), clobbers(len(streams))))
+            % (text, outs, ', '.join(inputs + [CONSTS[k] for k in used]), clobbers(len(streams))))
 
 
-def halves(name, k):
-    return ['[%s%d0] "v"((u32)(%s%d))' % (name, k, name, k), '[%s%d1] "v"((u32)(%s%d >> 32))' % (name, k, name, k)]
+def halves(name, expr):
+    """asm input operands for the two halves of a 64-bit C expression"""
+    return ['[%s0] "v"((u32)(%s))' % (name, expr), '[%s1] "v"((u32)((%s) >> 32))' % (name, expr)]
 
 
 def butterflies(r):
@@ -234,7 +315,7 @@ def trivial(i, r):
     return (i & ((1 << r) - 1)) == 0
 
 
-def gen_bfly_group(mode, r, grp, triv):
+def gen_bfly_group(arith, mode, r, grp, triv):
     bfs = butterflies(r)[4 * grp:4 * grp + 4]
     streams, inputs, regs = [], [], []
     for k, (a, b) in enumerate(bfs):
@@ -242,14 +323,44 @@ def gen_bfly_group(mode, r, grp, triv):
         regs += [a, b]
         if triv and trivial(a, r):
             streams.append(bf_plain(S, 2 * a, 2 * b))
-        else:
-            inputs += halves('w', k)
-            fn = bf_fwd if mode == 'MODE_FWD' else bf_inv
-            streams.append(fn(S, 2 * a, 2 * b, '%%[w%d0]' % k, '%%[w%d1]' % k))
-    s = 'template <> struct BflyGroup<%s, %d, %d, %s> {\n' % (mode, r, grp, 'true' if triv else 'false')
+            continue
+        W = ['%%[w%d0]' % k, '%%[w%d1]' % k]
+        inputs += halves('w%d' % k, 'w%d' % k)
+        if arith == 'ARITH_SHOUP':
+            W += ['%%[p%d0]' % k, '%%[p%d1]' % k]
+            inputs += halves('p%d' % k, 'p%d' % k)
+        fn = bf_fwd_a if mode == 'MODE_FWD' else bf_inv_a
+        streams.append(fn(arith, S, 2 * a, 2 * b, W))
+    s = 'template <> struct BflyGroup<%s, %s, %d, %d, %s> {\n' % (arith, mode, r, grp, 'true' if triv else 'false')
     s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 w0, u64 w1, u64 w2, u64 w3,\n'
-          '                                             const AsmConsts &c) {\n')
+          '                                             u64 p0, u64 p1, u64 p2, u64 p3, const AsmConsts &c) {\n')
     s += asm_stmt(streams, sorted(regs), inputs)
+    s += '  }\n};\n'
+    return s
+
+
+def twist_width(arith):
+    """elements per twist statement: the FixedPoint64 back end brings four words per element"""
+    return 2 if arith == 'ARITH_SHOUP' else 4
+
+
+def gen_twist_group(arith, grp):
+    streams, inputs = [], []
+    tw = twist_width(arith)
+    for k in range(tw):
+        H = ['%%[h%d0]' % k, '%%[h%d1]' % k]
+        L = ['%%[l%d0]' % k, '%%[l%d1]' % k]
+        inputs += halves('h%d' % k, 'h[%d]' % k) + halves('l%d' % k, 'l[%d]' % k)
+        if arith == 'ARITH_SHOUP':
+            H += ['%%[hp%d0]' % k, '%%[hp%d1]' % k]
+            L += ['%%[lp%d0]' % k, '%%[lp%d1]' % k]
+            inputs += halves('hp%d' % k, 'hp[%d]' % k) + halves('lp%d' % k, 'lp[%d]' % k)
+        streams.append(twist_a(arith, Slot(k), 2 * (tw * grp + k), H, L))
+    s = 'template <> struct TwistGroup<%s, %d> {\n' % (arith, grp)
+    s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], const u64 (&h)[%d], const u64 (&l)[%d],\n'
+          '                                             const u64 (&hp)[%d], const u64 (&lp)[%d],\n'
+          '                                             const AsmConsts &c) {\n' % (tw, tw, tw, tw))
+    s += asm_stmt(streams, range(tw * grp, tw * grp + tw), inputs)
     s += '  }\n};\n'
     return s
 
@@ -258,7 +369,7 @@ def gen_mont_group(grp):
     streams, inputs = [], []
     for k in range(4):
         streams.append(mul_inplace(Slot(k), 2 * (4 * grp + k), '%%[w%d0]' % k, '%%[w%d1]' % k))
-        inputs += halves('w', k)
+        inputs += halves('w%d' % k, 'w%d' % k)
     s = 'template <> struct MontGroup<%d> {\n' % grp
     s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 w0, u64 w1, u64 w2, u64 w3,\n'
           '                                             const AsmConsts &c) {\n')
@@ -267,23 +378,8 @@ def gen_mont_group(grp):
     return s
 
 
-def gen_twist_group(grp):
-    streams, inputs = [], []
-    for k in range(4):
-        streams.append(mul_composed(Slot(k), 2 * (4 * grp + k), '%%[hi%d0]' % k, '%%[hi%d1]' % k,
-                                    '%%[lo%d0]' % k, '%%[lo%d1]' % k))
-        inputs += halves('hi', k) + halves('lo', k)
-    s = 'template <> struct TwistGroup<%d> {\n' % grp
-    s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 hi0, u64 hi1, u64 hi2, u64 hi3,\n'
-          '                                             u64 lo0, u64 lo1, u64 lo2, u64 lo3,\n'
-          '                                             const AsmConsts &c) {\n')
-    s += asm_stmt(streams, range(4 * grp, 4 * grp + 4), inputs)
-    s += '  }\n};\n'
-    return s
-
-
 def gen_scale_group(r, grp):
-    """x0 of every butterfly of BflyGroup<., r, grp, .> times a wave-uniform factor"""
+    """x0 of every butterfly of BflyGroup<., ., r, grp, .> times a wave-uniform factor"""
     bfs = butterflies(r)[4 * grp:4 * grp + 4]
     streams = [mul_inplace(Slot(k), 2 * a, '%[s0]', '%[s1]') for k, (a, _) in enumerate(bfs)]
     s = 'template <> struct ScaleGroup<%d, %d> {\n' % (r, grp)
@@ -293,7 +389,7 @@ def gen_scale_group(r, grp):
     return s
 
 
-HEADER = '''// GENERATED by gen_stage_asm.py -- do not edit; regenerate with
+HEADER = """// GENERATED by gen_stage_asm.py -- do not edit; regenerate with
 //     python sve_ntt_amd/csrc/gen_stage_asm.py > sve_ntt_amd/csrc/stage_asm.inc
 // The butterfly stages of an E = 16 tile step as gfx950 assembly on fixed registers (x_i =
 // v[2i:2i+1]); see the generator's docstring for the why and the register map.  Included by
@@ -303,30 +399,39 @@ struct AsmConsts {
   u64 N, negN;
   u32 n0, n1, ni0, ni1;
   u64 save;  // EXEC at kernel entry (all lanes of a live workgroup)
+  u32 nn0, nn1;  // the words of negN = 2^64 - N (Goldilocks: nn0 = eps = 2^32 - 1)
 };
 
-// four butterflies (x_a, x_a + 2^R) of stage bit R: the GRP-th four in ascending a.
-// TRIV: the stage's twiddles with (a mod 2^R) == 0 are omega^0 (lowest step of a transform).
-template <int MODE, int R, int GRP, bool TRIV> struct BflyGroup;
-// x[4 GRP + k] *= w_k
+// four butterflies (x_a, x_a + 2^R) of stage bit R: the GRP-th four in ascending a, in the
+// arithmetic back end ARITH (field64.h); w_k / p_k: twiddle of the k-th and, for ARITH_SHOUP,
+// its precomputed companion.  TRIV: the stage's twiddles with (a mod 2^R) == 0 are omega^0
+// (lowest step of a transform) and those butterflies multiply by nothing.
+template <int ARITH, int MODE, int R, int GRP, bool TRIV> struct BflyGroup;
+// x[W GRP + k] *= hi_k * lo_k, k < W, in the back end's domain; W = 4, or 2 for ARITH_SHOUP
+// (hp / lp: its precomputed companions -- four words per element)
+template <int ARITH, int GRP> struct TwistGroup;
+// x[4 GRP + k] *= w_k * 2^-64 (Montgomery product, whatever the back end)
 template <int GRP> struct MontGroup;
-// x[4 GRP + k] *= hi_k * lo_k
-template <int GRP> struct TwistGroup;
-// the first elements of BflyGroup<., R, GRP, .>'s butterflies times s
+// the first elements of BflyGroup<., ., R, GRP, .>'s butterflies times s * 2^-64
 template <int R, int GRP> struct ScaleGroup;
-'''
+"""
 
 
 def main():
+    only = sys.argv[1:] or ARITHS
     out = [HEADER]
-    for mode in ('MODE_FWD', 'MODE_INV'):
-        for r in range(4):
-            for grp in range(2):
-                for triv in (False, True):
-                    out.append(gen_bfly_group(mode, r, grp, triv))
+    for arith in ARITHS:
+        if arith not in only:
+            continue
+        for mode in ('MODE_FWD', 'MODE_INV'):
+            for r in range(4):
+                for grp in range(2):
+                    for triv in (False, True):
+                        out.append(gen_bfly_group(arith, mode, r, grp, triv))
+        for grp in range(16 // twist_width(arith)):
+            out.append(gen_twist_group(arith, grp))
     for grp in range(4):
         out.append(gen_mont_group(grp))
-        out.append(gen_twist_group(grp))
     for r in range(4):
         for grp in range(2):
             out.append(gen_scale_group(r, grp))

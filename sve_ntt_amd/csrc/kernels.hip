@@ -5,53 +5,10 @@
 // layer/sve/blocked-generic.hpp:139-154, or one row in kernel/recursive.hpp:69-74).
 #include <hip/hip_runtime.h>
 
-#include <atomic>
-
 #include "kernels.h"
-#include "tile_ntt.h"
+#include "tile_launch.h"
 
 namespace sventt_hip {
-
-template <class TN, int IDX>
-__device__ __forceinline__ void run_steps(const PassArgs &a, const typename TN::Tile &t, u32 tid,
-                                          u64 *lds) {
-  constexpr int SI = (TN::MODE == MODE_FWD) ? IDX : TN::NSTEPS - 1 - IDX;
-  TN::template step<SI, (IDX > 0)>(a, t, tid, lds);
-  if constexpr (IDX + 1 < TN::NSTEPS) run_steps<TN, IDX + 1>(a, t, tid, lds);
-}
-
-// E = 16 tiles are sized for four waves per SIMD (two 512-thread workgroups per CU with their
-// 64 KiB tiles, or four 256-thread ones): keep the register allocator inside 128 VGPRs.
-template <class TN>
-__global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1) void tile_kernel(const PassArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64 *lds = reinterpret_cast<u64 *>(smem);
-  const typename TN::Tile t = TN::locate(a, blockIdx.x);
-  if (!t.live) return;  // whole workgroup: no barrier is skipped by part of it
-  run_steps<TN, 0>(a, t, threadIdx.x, lds);
-}
-
-template <class TN>
-static hipError_t launch_tile(const PassArgs &a, u32 grid, hipStream_t stream) {
-  constexpr size_t lds_bytes = (TN::NSTEPS > 1) ? (sizeof(u64) << TN::LOGT) : 0;
-  if constexpr (lds_bytes > 48 * 1024) {
-    // the opt-in to more than 48 KiB of dynamic LDS is a per-device property of the function:
-    // one bit per device ordinal, set once the attribute call succeeded there
-    static std::atomic<uint64_t> done{0};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel<TN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return e;
-      done.fetch_or(bit, std::memory_order_release);
-    }
-  }
-  hipLaunchKernelGGL(tile_kernel<TN>, dim3(grid), dim3(TN::NT), lds_bytes, stream, a);
-  return hipGetLastError();
-}
 
 // dst[i] = a[i]*b[i] mod p (both plain residues < p): montmul(a, b) = a*b/R, then *R^2/R.
 // HBM-bound (24 B per element): two elements per thread through 16-byte accesses
@@ -207,14 +164,16 @@ hipError_t launch_transpose_inplace(u64 *m, u64 dim, hipStream_t stream) {
 }
 
 // ---- registry -------------------------------------------------------------------
-template <class TN> struct HipLauncher {
-  static hipError_t launch(const PassArgs &a, u32 grid, hipStream_t stream) {
-    return launch_tile<TN>(a, grid, stream);
+const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge, int arith) {
+  switch (arith) {
+    case ARITH_MONT:
+      return find_kernel_in_registry<KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge);
+    case ARITH_GOLD:
+      return find_kernel_gold(kind, logl, dir, flag, f0, loge);
+    case ARITH_SHOUP:
+      return find_kernel_shoup(kind, logl, dir, flag, f0, loge);
   }
-};
-
-const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge) {
-  return find_kernel_in_registry<KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge);
+  return nullptr;
 }
 
 }  // namespace sventt_hip

@@ -82,12 +82,12 @@ int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
   for (size_t i = 0; i < host.size(); ++i) {
     const HostPass &h = host[i];
     DevicePass &d = dev[i];
-    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
+    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge, h.arith);
     if (!d.kernel) return fail(SVENTT_ERR_LOGIC, "no kernel instantiated for this pass shape");
     if (d.kernel->f0 != h.f0 || d.kernel->logt != h.logt)
       return fail(SVENTT_ERR_LOGIC, "planner and kernel registry disagree on the tile shape");
     if (h.kind == KIND_ROW && !h.inverse && !h.flag)
-      d.kernel_multiply = find_kernel(KIND_ROW, h.logl, MODE_FWD, 1, h.f0, h.loge);
+      d.kernel_multiply = find_kernel(KIND_ROW, h.logl, MODE_FWD, 1, h.f0, h.loge, h.arith);
     int rc;
     if ((rc = upload(h.stage, d.stage))) return rc;
     if ((rc = upload(h.twist_lo, d.twist_lo))) return rc;

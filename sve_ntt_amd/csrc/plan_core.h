@@ -36,6 +36,7 @@ struct HostPass {
   u64 grid = 0;
   int f0 = 0, logt = 0;
   int loge = REG_LOGE;  // elements per thread (log2): REG_LOGE, or FINE_LOGE for small totals
+  int arith = ARITH_MONT;  // back end of the butterflies and the twist; fixes the table format
   std::vector<u64> stage, twist_lo, twist_hi;
   u32 twist_shift = 0;
   u64 twist_col_offset = 0;
@@ -49,6 +50,7 @@ struct HostPlan {
   u64 r2 = 0;  // 2^128 mod N
   u64 inverse_scale = 1;  // what the inverse multiplies by (plain residue): n^{-1} unless asked otherwise
   std::vector<HostPass> fwd, inv;
+  int arith = ARITH_MONT;  // field64.h: chosen from the modulus and the plan flags
   bool fine = false;  // E = 4 tiles (registry.h): n * batch too small to fill the chip otherwise
   bool sharded = false;
   int rank = 0, nranks = 1;
@@ -60,7 +62,40 @@ enum : int {
   PLAN_ERR_INVALID_ARGUMENT = -1,
   PLAN_ERR_LOGIC = -4,
 };
-enum : u32 { PLAN_FORWARD = 1u, PLAN_INVERSE = 2u, PLAN_DEVICE_POINTERS = 4u, PLAN_KNOWN_FLAGS = 7u };
+enum : u32 {
+  PLAN_FORWARD = 1u,
+  PLAN_INVERSE = 2u,
+  PLAN_DEVICE_POINTERS = 4u,
+  PLAN_GENERIC_ARITHMETIC = 8u,  // Montgomery kernels even where a special back end exists
+  PLAN_FIXED_POINT = 16u,        // the FixedPoint64 (Shoup) back end; needs N < 2^63
+  PLAN_KNOWN_FLAGS = 31u
+};
+
+// Which back end a plan's kernels use (field64.h).  SVENTT_ARITH=mont|gold|shoup overrides the
+// choice for A/B measurements when the modulus allows it.
+inline int choose_arith(u64 p, u32 flags, std::string &err, int &arith) {
+  arith = ARITH_MONT;
+  if (flags & PLAN_FIXED_POINT) {
+    if (flags & PLAN_GENERIC_ARITHMETIC) {
+      err = "SVENTT_GENERIC_ARITHMETIC and SVENTT_FIXED_POINT exclude each other";
+      return -1;
+    }
+    if (p >> 63) {
+      err = "the FixedPoint64 back end needs a modulus below 2^63";  // c = a*w - q*N must fit [0, 2N)
+      return -1;
+    }
+    arith = ARITH_SHOUP;
+  } else if (!(flags & PLAN_GENERIC_ARITHMETIC) && p == GOLDILOCKS_N) {
+    arith = ARITH_GOLD;
+  }
+  if (const char *e = std::getenv("SVENTT_ARITH")) {
+    const std::string v(e);
+    if (v == "mont") arith = ARITH_MONT;
+    if (v == "gold" && p == GOLDILOCKS_N) arith = ARITH_GOLD;
+    if (v == "shoup" && !(p >> 63)) arith = ARITH_SHOUP;
+  }
+  return 0;
+}
 
 // Tuning knobs (environment, read once).  SVENTT_COL_SLIM=0/1: 4-column instead of
 // 8-column tiles for column passes of length >= 2^10 (two workgroups per CU).
@@ -106,42 +141,46 @@ inline int ilog2_u64(u64 x) {
 // entry j = root_{2^(p+1)}^j in Montgomery form; `top_scale` (plain) multiplies
 // the top stage's entries (inverse ROW passes that fold 1/L).
 inline std::vector<u64> build_stage_table(const Field &f, u64 gen, int logl, bool inverse,
-                                          u64 top_scale) {
+                                          u64 top_scale, int arith = ARITH_MONT) {
   const u64 N = f.N;
   const u64 L = 1ull << logl;
-  std::vector<u64> t(L > 1 ? L - 1 : 1, 0);
+  std::vector<u64> t;  // entry (2^p - 1 + j) in the back end's format (h_push_twiddle)
+  t.reserve((size_t)(L > 1 ? L - 1 : 1) * (arith == ARITH_SHOUP ? 2 : 1));
   for (int p = 0; p < logl; ++p) {
     const u64 order = 2ull << p;
     u64 w = h_powmod(gen, (N - 1) / order, N);
     if (inverse) w = h_invmod(w, N);
     u64 cur = (p == logl - 1) ? top_scale % N : 1;
     for (u64 j = 0; j < (1ull << p); ++j) {
-      t[(1ull << p) - 1 + j] = h_to_montgomery(cur, N);
+      h_push_twiddle(t, arith, cur, N);
       cur = h_mulmod(cur, w, N);
     }
   }
+  if (t.empty()) t.push_back(0);
   return t;
 }
 
 // omega_M^e = hi[e >> shift] * lo[e & mask]; `scale` (plain) is folded into hi.
 inline void build_twist_tables(const Field &f, u64 gen, int logm, bool inverse, u64 scale,
-                               std::vector<u64> &lo, std::vector<u64> &hi, u32 &shift) {
+                               std::vector<u64> &lo, std::vector<u64> &hi, u32 &shift,
+                               int arith = ARITH_MONT) {
   const u64 N = f.N;
   u64 w = h_powmod(gen, (N - 1) >> logm, N);
   if (inverse) w = h_invmod(w, N);
   shift = (u32)((logm + 1) / 2);
   if (tuning().twist_lo_log2 > 0 && (int)shift > tuning().twist_lo_log2) shift = (u32)tuning().twist_lo_log2;
-  lo.resize(1ull << shift);
-  hi.resize(1ull << (logm - (int)shift));
+  const u64 nlo = 1ull << shift, nhi = 1ull << (logm - (int)shift);
+  lo.clear();
+  hi.clear();
   u64 cur = 1;
-  for (u64 i = 0; i < lo.size(); ++i) {
-    lo[i] = h_to_montgomery(cur, N);
+  for (u64 i = 0; i < nlo; ++i) {
+    h_push_twiddle(lo, arith, cur, N);
     cur = h_mulmod(cur, w, N);
   }
   const u64 wbig = h_powmod(w, 1ull << shift, N);
   cur = scale % N;
-  for (u64 i = 0; i < hi.size(); ++i) {
-    hi[i] = h_to_montgomery(cur, N);
+  for (u64 i = 0; i < nhi; ++i) {
+    h_push_twiddle(hi, arith, cur, N);
     cur = h_mulmod(cur, wbig, N);
   }
 }
@@ -160,8 +199,9 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
   ps.dst_ostride = ps.src_ostride = ps.block;
   ps.twist_col_offset = col_offset;
   ps.loge = pl.fine ? FINE_LOGE : REG_LOGE;
+  ps.arith = pl.arith;
   const bool fold_row_scale = (kind == KIND_ROW) && inverse && flag;
-  ps.stage = build_stage_table(f, pl.g, logl, inverse, fold_row_scale ? scale_plain : 1);
+  ps.stage = build_stage_table(f, pl.g, logl, inverse, fold_row_scale ? scale_plain : 1, pl.arith);
   if (fold_row_scale) ps.scale = h_to_montgomery(scale_plain % f.N, f.N);
   u64 tiles;
   if (kind == KIND_COL) {
@@ -174,7 +214,7 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
       return PLAN_ERR_INVALID_ARGUMENT;
     }
     build_twist_tables(f, pl.g, twist_order_log2, inverse, inverse ? scale_plain : 1, ps.twist_lo,
-                       ps.twist_hi, ps.twist_shift);
+                       ps.twist_hi, ps.twist_shift, pl.arith);
     ps.f0 = pl.fine ? registry_fine_col_f0(logl, ilog2_u64(S))
                     : registry_col_f0(logl, ilog2_u64(S), tuning().col_slim);
     if (ps.f0 < 0 || !is_pow2(S)) {
@@ -334,6 +374,7 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
     return PLAN_ERR_INVALID_ARGUMENT;
   }
   init_field(pl, p, g);
+  if (choose_arith(p, flags, err, pl.arith)) return PLAN_ERR_INVALID_ARGUMENT;
   pl.n = n;
   pl.batch = batch;
   pl.total = n * batch;
@@ -351,7 +392,7 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   std::vector<int> cols;
   int row = 0;
   // small totals run on the fine (E = 4) tiles, provided they cover the requested split
-  pl.fine = tuning().fine && pl.total <= (1ull << tuning().fine_max_total_log2) &&
+  pl.fine = tuning().fine && pl.arith == ARITH_MONT && pl.total <= (1ull << tuning().fine_max_total_log2) &&
             logn <= MAX_FINE_COL_LOGL + MAX_FINE_ROW_LOGL &&
             // 2^12 and 2^13 are one pass on the 2^12/2^13-element tiles, two on the fine ones
             (n0_log2 != 0 || logn <= MAX_FINE_ROW_LOGL || logn > MAX_ROW_LOGL);
@@ -423,6 +464,7 @@ inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int
     return PLAN_ERR_INVALID_ARGUMENT;
   }
   init_field(pl, p, g);
+  if (choose_arith(p, flags, err, pl.arith)) return PLAN_ERR_INVALID_ARGUMENT;
   pl.n = n;
   pl.batch = 1;
   pl.flags = flags;
@@ -477,6 +519,7 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
   const int logcl = logc - logg;
   const u64 Cl = 1ull << logcl, C = 1ull << logc, Rl = (1ull << r_log2) >> logg;
   init_field(pl, p, g);
+  if (choose_arith(p, flags, err, pl.arith)) return PLAN_ERR_INVALID_ARGUMENT;
   pl.n = C;  // length of the transforms this plan runs
   pl.batch = Rl;
   pl.total = Rl * C;
@@ -583,10 +626,14 @@ inline int make_chunk_args(const HostPlan &pl, const HostPass &ps, u64 *dst, con
 
 inline std::string describe_plan(const HostPlan &pl) {
   std::string d;
+  if (pl.arith == ARITH_GOLD) d = "[goldilocks] ";
+  if (pl.arith == ARITH_SHOUP) d = "[fixed-point] ";
   char buf[96];
   const std::vector<HostPass> &v = pl.fwd.empty() ? pl.inv : pl.fwd;
+  bool first = true;
   for (const HostPass &p : v) {
-    if (!d.empty()) d += " | ";
+    if (!first) d += " | ";
+    first = false;
     if (p.kind == KIND_COL)
       snprintf(buf, sizeof buf, "col 2^%d x T%d (stride %llu%s)", p.logl, 1 << p.f0,
                (unsigned long long)p.istride, p.loge == FINE_LOGE ? ", E4" : "");

@@ -50,27 +50,27 @@ constexpr int row_logt(int logl) { return logl > 12 ? logl : 12; }
 // below (plan_core.h: Tuning::col_slim); the wide ones remain for SVENTT_COL_SLIM=0.
 constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
 
-template <int LOGL, int MODE, bool FLAG>
+template <int LOGL, int MODE, bool FLAG, int ARITH = ARITH_MONT>
 using RowTile =
-    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowSteps<LOGL>::type>;
-template <int LOGL, int MODE>
+    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowSteps<LOGL>::type, ARITH>;
+template <int LOGL, int MODE, int ARITH = ARITH_MONT>
 using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
-                        typename DefaultSteps<LOGL>::type>;
+                        typename DefaultSteps<LOGL>::type, ARITH>;
 
 // Narrow COL tiles (T = 8 whatever the column length) for blocks with fewer
 // columns than the wide tile wants; tiny tiles, only met at small n.
 constexpr int NARROW_F0 = 3;
-template <int LOGL, int MODE>
+template <int LOGL, int MODE, int ARITH = ARITH_MONT>
 using ColTileNarrow = TileNTT<LOGL + NARROW_F0, NARROW_F0, LOGL, REG_LOGE, MODE, true,
-                              typename DefaultSteps<LOGL>::type>;
+                              typename DefaultSteps<LOGL>::type, ARITH>;
 
 // Slim COL tiles (T = 4, 32-byte segments; the XCD-aware tile order of
 // TileNTT::locate lets one L2 merge the two halves of a 64-byte line): half the
 // LDS of the T = 8 tile, so two workgroups share a CU.
 constexpr int SLIM_F0 = 2;
-template <int LOGL, int MODE>
+template <int LOGL, int MODE, int ARITH = ARITH_MONT>
 using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
-                            typename DefaultSteps<LOGL>::type>;
+                            typename DefaultSteps<LOGL>::type, ARITH>;
 
 // Fine tiles for transforms too small to fill the chip with 2^12-element tiles
 // (n * batch <= 2^21, e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
@@ -174,6 +174,39 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
       SVENTT_FINE_COL_ENTRIES(4), SVENTT_FINE_COL_ENTRIES(5), SVENTT_FINE_COL_ENTRIES(6),
       SVENTT_FINE_COL_ENTRIES(7), SVENTT_FINE_COL_ENTRIES(8), SVENTT_FINE_COL_ENTRIES(9),
       SVENTT_FINE_COL_ENTRIES(10),
+  };
+  for (const Entry &e : table)
+    if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0 &&
+        e.loge == loge)
+      return &e;
+  return nullptr;
+}
+
+// The E = 16 tiles of one of the other arithmetic back ends (field64.h: ARITH_GOLD,
+// ARITH_SHOUP); plans of those back ends never use the fine tiles.  Same shapes, same lookup.
+#define SVENTT_A_ROW(L)                                                                   \
+  make_entry<RowTile<L, MODE_FWD, false, ARITH>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0), \
+  make_entry<RowTile<L, MODE_FWD, true, ARITH>, Entry, Launcher>(KIND_ROW, MODE_FWD, 1),  \
+  make_entry<RowTile<L, MODE_INV, false, ARITH>, Entry, Launcher>(KIND_ROW, MODE_INV, 0), \
+  make_entry<RowTile<L, MODE_INV, true, ARITH>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
+#define SVENTT_A_COL(T, L)                                                         \
+  make_entry<T<L, MODE_FWD, ARITH>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),        \
+  make_entry<T<L, MODE_INV, ARITH>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
+
+template <int ARITH, class Entry, template <class> class Launcher>
+const Entry *find_arith_kernel_in_registry(int kind, int logl, int dir, int flag, int f0, int loge) {
+  static const Entry table[] = {
+      SVENTT_A_COL(ColTileNarrow, 1), SVENTT_A_COL(ColTileNarrow, 2), SVENTT_A_COL(ColTileNarrow, 3),
+      SVENTT_A_COL(ColTileNarrow, 4), SVENTT_A_COL(ColTileNarrow, 5), SVENTT_A_COL(ColTileNarrow, 6),
+      SVENTT_A_COL(ColTileNarrow, 7), SVENTT_A_COL(ColTileNarrow, 8),
+      SVENTT_A_ROW(1),  SVENTT_A_ROW(2),  SVENTT_A_ROW(3),  SVENTT_A_ROW(4),  SVENTT_A_ROW(5),
+      SVENTT_A_ROW(6),  SVENTT_A_ROW(7),  SVENTT_A_ROW(8),  SVENTT_A_ROW(9),  SVENTT_A_ROW(10),
+      SVENTT_A_ROW(11), SVENTT_A_ROW(12), SVENTT_A_ROW(13),
+      SVENTT_A_COL(ColTile, 1), SVENTT_A_COL(ColTile, 2), SVENTT_A_COL(ColTile, 3),
+      SVENTT_A_COL(ColTile, 4), SVENTT_A_COL(ColTile, 5), SVENTT_A_COL(ColTile, 6),
+      SVENTT_A_COL(ColTile, 7), SVENTT_A_COL(ColTile, 8), SVENTT_A_COL(ColTile, 9),
+      SVENTT_A_COL(ColTile, 10), SVENTT_A_COL(ColTile, 11),
+      SVENTT_A_COL(ColTileSlim, 10), SVENTT_A_COL(ColTileSlim, 11), SVENTT_A_COL(ColTileSlim, 12),
   };
   for (const Entry &e : table)
     if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0 &&

@@ -111,9 +111,15 @@ F64_HD u32 bitrev32(u32 x) {
 // FLAG: COL tiles -> apply the pass twist (store side forward, load side inverse);
 //       ROW inverse tiles -> fold the 1/L scaling into the top stage;
 //       ROW forward tiles -> multiply by PassArgs::epilogue on the way out.
-template <int LOGT_, int F0_, int LOGL_, int LOGE_, int MODE_, bool FLAG_, class STEPS_>
+// ARITH: the arithmetic back end of the butterflies and of the twist (field64.h); the fold of
+// 1/L and the fused product always use the Montgomery product (their operands arrive in
+// Montgomery form whatever the back end).
+template <int LOGT_, int F0_, int LOGL_, int LOGE_, int MODE_, bool FLAG_, class STEPS_,
+          int ARITH_ = ARITH_MONT>
 struct TileNTT {
   static constexpr int LOGT = LOGT_, F0 = F0_, LOGL = LOGL_, LOGE = LOGE_, MODE = MODE_;
+  static constexpr int ARITH = ARITH_;
+  static constexpr int TWW = Arith<ARITH_>::TW_WORDS;  // 64-bit words per table entry
   static constexpr bool FLAG = FLAG_;
   using STEPS = STEPS_;
   static constexpr int E = 1 << LOGE;
@@ -194,19 +200,28 @@ struct TileNTT {
     for (int b = 0; b < LOGL; ++b) r |= ((x >> b) & 1u) << (LOGL - 1 - b);
     return r;
   }
-  F64_HD static u64 twist_lookup(const PassArgs &a, u32 e) {
-    const u64 lo = a.twist_lo[e & ((1u << a.twist_shift) - 1u)];
-    const u64 hi = a.twist_hi[e >> a.twist_shift];
-    return montmul(hi, lo, a.f);
+  // x * omega_M^e with omega_M^e = hi[e >> shift] * lo[e & mask] (C++ path)
+  F64_HD static u64 twist_apply_cxx(const PassArgs &a, u64 x, u32 e) {
+    const u64 *lo = a.twist_lo + (size_t)(e & ((1u << a.twist_shift) - 1u)) * TWW;
+    const u64 *hi = a.twist_hi + (size_t)(e >> a.twist_shift) * TWW;
+    if constexpr (ARITH == ARITH_SHOUP) {
+      // the product hi*lo would need its own precomputed companion: multiply twice instead
+      return Arith<ARITH>::mul(Arith<ARITH>::mul(x, hi, a.f), lo, a.f);
+    } else {
+      const u64 tw = Arith<ARITH>::mul(hi[0], lo, a.f);
+      return Arith<ARITH>::mul(x, &tw, a.f);
+    }
   }
 
 #if defined(SVENTT_STAGE_ASM)
   // first element of the b-th butterfly (ascending) of stage bit r over 16 registers
   static constexpr int bf_first(int r, int b) { return ((b >> r) << (r + 1)) | (b & ((1 << r) - 1)); }
 
-  // Looked-up halves of the twist factors of four elements (x[4 GRP .. 4 GRP + 3]).
+  // Looked-up halves of the twist factors of TWG elements (x[TWG GRP .. TWG GRP + TWG - 1]).
+  static constexpr int TWG = (ARITH == ARITH_SHOUP) ? 2 : 4;
   struct TwistFactors {
-    u64 h[4], l[4];
+    u64 h[TWG], l[TWG];
+    u64 hp[TWG], lp[TWG];  // ARITH_SHOUP: the precomputed companions
   };
   template <int k, int LO, int GRP>
   __device__ __forceinline__ static TwistFactors twist_load(const PassArgs &a, const Tile &t,
@@ -214,19 +229,29 @@ struct TileNTT {
     constexpr int R = 1 << k;
     TwistFactors f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 4 * GRP + q, g = i >> k, v = i & (R - 1);
+    for (int q = 0; q < TWG; ++q) {
+      const int i = TWG * GRP + q, g = i >> k, v = i & (R - 1);
       const u32 col = twist_col(a, t, I0[g]);
       const u32 e = twist_e0(col, I0[g]) + col * twist_bv(v, LO);
-      f.l[q] = a.twist_lo[e & ((1u << a.twist_shift) - 1u)];
-      f.h[q] = a.twist_hi[e >> a.twist_shift];
+      const u64 *lo = a.twist_lo + (size_t)(e & ((1u << a.twist_shift) - 1u)) * TWW;
+      const u64 *hi = a.twist_hi + (size_t)(e >> a.twist_shift) * TWW;
+      if constexpr (TWW == 2) {
+        const ulonglong2 lv = *reinterpret_cast<const ulonglong2 *>(lo);
+        const ulonglong2 hv = *reinterpret_cast<const ulonglong2 *>(hi);
+        f.l[q] = lv.x, f.lp[q] = lv.y, f.h[q] = hv.x, f.hp[q] = hv.y;
+      } else {
+        f.l[q] = lo[0], f.h[q] = hi[0];
+      }
     }
     return f;
   }
   // x[4 GRP + q] *= h[q] * l[q]   (twist_lookup + montmul of the C++ path, one assembly group)
   template <int GRP>
   __device__ __forceinline__ static void twist_apply(u64 (&x)[E], const TwistFactors &f, const AsmConsts &c) {
-    TwistGroup<GRP>::run(x, f.h[0], f.h[1], f.h[2], f.h[3], f.l[0], f.l[1], f.l[2], f.l[3], c);
+    if constexpr (ARITH == ARITH_SHOUP)
+      TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.hp, f.lp, c);
+    else
+      TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.h, f.l, c);  // no companions: the arrays are ignored
   }
   // all 16 elements; the factors of group g + 1 are requested before group g's ~230 VALU
   // instructions run.  `f0` holds group 0's, requested by the caller.
@@ -234,13 +259,32 @@ struct TileNTT {
   __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                    const u32 (&I0)[E >> k], const TwistFactors &f0,
                                                    const AsmConsts &c) {
-    const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
-    twist_apply<0>(x, f0, c);
-    const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
-    twist_apply<1>(x, f1, c);
-    const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
-    twist_apply<2>(x, f2, c);
-    twist_apply<3>(x, f3, c);
+    if constexpr (ARITH == ARITH_SHOUP) {
+      // four words per element: two elements per statement, the next pair requested ahead
+      const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
+      twist_apply<0>(x, f0, c);
+      const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
+      twist_apply<1>(x, f1, c);
+      const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
+      twist_apply<2>(x, f2, c);
+      const TwistFactors f4 = twist_load<k, LO, 4>(a, t, I0);
+      twist_apply<3>(x, f3, c);
+      const TwistFactors f5 = twist_load<k, LO, 5>(a, t, I0);
+      twist_apply<4>(x, f4, c);
+      const TwistFactors f6 = twist_load<k, LO, 6>(a, t, I0);
+      twist_apply<5>(x, f5, c);
+      const TwistFactors f7 = twist_load<k, LO, 7>(a, t, I0);
+      twist_apply<6>(x, f6, c);
+      twist_apply<7>(x, f7, c);
+    } else {
+      const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
+      twist_apply<0>(x, f0, c);
+      const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
+      twist_apply<1>(x, f1, c);
+      const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
+      twist_apply<2>(x, f2, c);
+      twist_apply<3>(x, f3, c);
+    }
   }
 
   // Operands of the fused pointwise product (ROW forward with FLAG) for x[4 GRP .. 4 GRP + 3].
@@ -281,7 +325,8 @@ struct TileNTT {
     constexpr bool twist_out = COL && FLAG && MODE == MODE_FWD && to_hbm;
     constexpr bool multiply_out = !COL && FLAG && MODE == MODE_FWD && to_hbm;
     const AsmConsts c{a.f.N, a.f.negN, (u32)a.f.N, (u32)(a.f.N >> 32), (u32)a.f.Ninv,
-                      (u32)(a.f.Ninv >> 32), __builtin_amdgcn_read_exec()};
+                      (u32)(a.f.Ninv >> 32), __builtin_amdgcn_read_exec(), (u32)a.f.negN,
+                      (u32)(a.f.negN >> 32)};
     u64 x[E];
     u32 I0[G], s_low[G];
 #pragma unroll
@@ -290,8 +335,9 @@ struct TileNTT {
       s_low[g] = s & ((1u << lo) - 1u);
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
-    u64 w0[8];  // first stage's twiddles: requested ahead of the barrier and of the data
-    stage_twiddles<k, LO, lo, 0>(a, s_low, w0);
+    // first stage's twiddles: requested ahead of the barrier and of the data
+    const GroupTwiddles w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low);
+    const GroupTwiddles w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low);
     if constexpr (SYNC) __syncthreads();
     // ---- gather ------------------------------------------------------------
 #pragma unroll
@@ -316,7 +362,7 @@ struct TileNTT {
     // ---- k fused stages ------------------------------------------------------
     TwistFactors f0;
     Operands o0;
-    stages_asm<k, LO, lo, 0, twist_out, multiply_out>(a, t, x, I0, s_low, w0, f0, o0, c);
+    stages_asm<k, LO, lo, 0, twist_out, multiply_out>(a, t, x, I0, s_low, w0, w1, f0, o0, c);
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
       if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, c);
@@ -353,46 +399,78 @@ struct TileNTT {
 
   // twiddles of the eight butterflies of stage rr of the step (forward walks the stage bits
   // downwards, inverse upwards); omega^0 entries of a lowest step are not loaded
-  template <int k, int LO, int lo, int rr>
-  __device__ __forceinline__ static void stage_twiddles(const PassArgs &a, const u32 (&s_low)[E >> k],
-                                                        u64 (&w)[8]) {
+  // A lowest step's twiddles with index 0 are omega^0 and their butterflies multiply by nothing
+  // -- unless the stage is the top stage of an inverse ROW pass that folds 1/L, whose table
+  // holds (1/L) * omega^j (transforms of 2 and 4 points have both in one step).
+  template <int LO, int ps> static constexpr bool stage_has_unit_twiddles() {
+    return LO == 0 && !(!COL && FLAG && MODE == MODE_INV && ps == LOGL - 1);
+  }
+
+  // Twiddles of the GRP-th four butterflies of stage rr of the step (forward walks the stage
+  // bits downwards, inverse upwards); omega^0 entries of a lowest step are not loaded.
+  struct GroupTwiddles {
+    u64 w[4];
+    u64 p[4];  // ARITH_SHOUP: the precomputed companions w' = floor(w * 2^64 / N)
+  };
+  template <int k, int LO, int lo, int rr, int GRP>
+  __device__ __forceinline__ static GroupTwiddles group_twiddles(const PassArgs &a, const u32 (&s_low)[E >> k]) {
     constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
     constexpr int ps = LO + r;
-    const u64 *tab = a.stage_tw + ((1u << ps) - 1u);
+    constexpr bool triv = stage_has_unit_twiddles<LO, ps>();
+    const u64 *tab = a.stage_tw + (size_t)((1u << ps) - 1u) * TWW;
+    GroupTwiddles tw;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int i = bf_first(r, b);
+    for (int q = 0; q < 4; ++q) {
+      const int i = bf_first(r, 4 * GRP + q);
       const int g = i >> k;
       const u32 vlow = (u32)(i & ((1 << r) - 1));
       const u32 j = ((vlow << lo) | s_low[g]) >> F0;
-      w[b] = (LO == 0 && vlow == 0) ? 0 : tab[j];
+      if (triv && vlow == 0) {
+        tw.w[q] = 0;
+        tw.p[q] = 0;
+      } else if constexpr (TWW == 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(tab + (size_t)j * 2);
+        tw.w[q] = v.x, tw.p[q] = v.y;
+      } else {
+        tw.w[q] = tab[j];
+        tw.p[q] = 0;
+      }
     }
+    return tw;
   }
 
-  // stage rr with its twiddles in w; the next stage's are requested before the butterflies run
-  // so that their L2 latency hides behind ~300 VALU instructions.  Ahead of the step's last
-  // stage the first group of what the scatter multiplies by is requested too (TW: twist
-  // factors into f0, MUL: operands of the fused product into o0).
+  // Stage rr of the step: two assembly groups of four butterflies.  Each group's twiddles
+  // were requested one group earlier (w0 / w1 on entry), and the same group of the NEXT stage
+  // is requested as soon as this one has consumed its own -- their L2 latency hides behind
+  // ~150 VALU instructions per thread and only two groups' worth of twiddle registers is live.
+  // Ahead of the step's last group the first quarter of what the scatter multiplies by is
+  // requested too (TW: twist factors into f0, MUL: operands of the fused product into o0).
   template <int k, int LO, int lo, int rr, bool TW, bool MUL>
   __device__ __forceinline__ static void stages_asm(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                     const u32 (&I0)[E >> k], const u32 (&s_low)[E >> k],
-                                                    const u64 (&w)[8], TwistFactors &f0, Operands &o0,
-                                                    const AsmConsts &c) {
+                                                    const GroupTwiddles &w0, const GroupTwiddles &w1,
+                                                    TwistFactors &f0, Operands &o0, const AsmConsts &c) {
     constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
     constexpr int ps = LO + r;
-    constexpr bool triv = (LO == 0);
-    u64 wn[8];
-    if constexpr (rr + 1 < k) stage_twiddles<k, LO, lo, rr + 1>(a, s_low, wn);
-    if constexpr (rr + 1 == k && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
-    if constexpr (rr + 1 == k && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
+    constexpr bool triv = stage_has_unit_twiddles<LO, ps>();
+    constexpr bool more = rr + 1 < k;
     if constexpr (!COL && FLAG && MODE == MODE_INV && ps == LOGL - 1) {
       // fold 1/L into the top stage: (c*x0) +- (c*w)*x1, the table holds c*w
       ScaleGroup<r, 0>::run(x, a.scale, c);
       ScaleGroup<r, 1>::run(x, a.scale, c);
     }
-    BflyGroup<MODE, r, 0, triv>::run(x, w[0], w[1], w[2], w[3], c);
-    BflyGroup<MODE, r, 1, triv>::run(x, w[4], w[5], w[6], w[7], c);
-    if constexpr (rr + 1 < k) stages_asm<k, LO, lo, rr + 1, TW, MUL>(a, t, x, I0, s_low, wn, f0, o0, c);
+    BflyGroup<ARITH, MODE, r, 0, triv>::run(x, w0.w[0], w0.w[1], w0.w[2], w0.w[3], w0.p[0], w0.p[1], w0.p[2],
+                                            w0.p[3], c);
+    GroupTwiddles n0;
+    if constexpr (more) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low);
+    if constexpr (!more && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
+    if constexpr (!more && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
+    BflyGroup<ARITH, MODE, r, 1, triv>::run(x, w1.w[0], w1.w[1], w1.w[2], w1.w[3], w1.p[0], w1.p[1], w1.p[2],
+                                            w1.p[3], c);
+    if constexpr (more) {
+      const GroupTwiddles n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low);
+      stages_asm<k, LO, lo, rr + 1, TW, MUL>(a, t, x, I0, s_low, n0, n1, f0, o0, c);
+    }
   }
 #endif  // SVENTT_STAGE_ASM
 
@@ -440,17 +518,13 @@ struct TileNTT {
       if constexpr (from_hbm) {
         const u64 vstride = COL ? (a.src_istride << LO) : (1ull << lo);
         const u64 *p0 = a.src + saddr(a, t, I0);
-        u64 tw[R];
-        if constexpr (twisted && MODE == MODE_INV) {
-#pragma unroll
-          for (int v = 0; v < R; ++v) tw[v] = twist_lookup(a, tw_e0 + tw_col * twist_bv(v, LO));
-        }
 #pragma unroll
         for (int v = 0; v < R; ++v)
           x[g * R + v] = in_range(a, t, I0 | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
         if constexpr (twisted && MODE == MODE_INV) {
 #pragma unroll
-          for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], tw[v], a.f);
+          for (int v = 0; v < R; ++v)
+            x[g * R + v] = twist_apply_cxx(a, x[g * R + v], tw_e0 + tw_col * twist_bv(v, LO));
         }
       } else {
 #pragma unroll
@@ -462,7 +536,7 @@ struct TileNTT {
         // forward walks the stage bits downwards, inverse upwards
         const int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
         const int ps = LO + r;  // stage bit inside the transform: span 2^ps
-        const u64 *tab = a.stage_tw + ((1u << ps) - 1u);
+        const u64 *tab = a.stage_tw + (size_t)((1u << ps) - 1u) * TWW;
 #pragma unroll
         for (int v = 0; v < R; ++v) {
           if (v & (1 << r)) continue;
@@ -474,16 +548,16 @@ struct TileNTT {
             if (trivial)
               butterfly_fwd(x0, x1, a.f);
             else
-              butterfly_fwd(x0, x1, tab[j], a.f);
+              butterfly_fwd_tw<ARITH>(x0, x1, tab + (size_t)j * TWW, a.f);
           } else {
             if (!COL && FLAG && ps == LOGL - 1) {
               // fold 1/L into the top stage: (c*x0) +- (c*w)*x1, table holds c*w
               x0 = montmul(x0, a.scale, a.f);
-              butterfly_inv(x0, x1, tab[j], a.f);
+              butterfly_inv_tw<ARITH>(x0, x1, tab + (size_t)j * TWW, a.f);
             } else if (trivial) {
               butterfly_inv(x0, x1, a.f);
             } else {
-              butterfly_inv(x0, x1, tab[j], a.f);
+              butterfly_inv_tw<ARITH>(x0, x1, tab + (size_t)j * TWW, a.f);
             }
           }
         }
@@ -493,11 +567,9 @@ struct TileNTT {
         const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
         u64 *p0 = a.dst + gaddr(a, t, I0);
         if constexpr (twisted && MODE == MODE_FWD) {
-          u64 tw[R];
 #pragma unroll
-          for (int v = 0; v < R; ++v) tw[v] = twist_lookup(a, tw_e0 + tw_col * twist_bv(v, LO));
-#pragma unroll
-          for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], tw[v], a.f);
+          for (int v = 0; v < R; ++v)
+            x[g * R + v] = twist_apply_cxx(a, x[g * R + v], tw_e0 + tw_col * twist_bv(v, LO));
         }
         if constexpr (!COL && FLAG && MODE == MODE_FWD) {
           const u64 *e0 = a.epilogue + gaddr(a, t, I0);

@@ -54,8 +54,13 @@ int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src, const u
   for (size_t i = 0; i < passes.size(); ++i) {
     const HostPass &h = passes[i];
     const bool fused = epilogue && i + 1 == passes.size();
-    const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-        h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, (h.flag || fused) ? 1 : 0, h.f0, h.loge);
+    const int dir = h.inverse ? MODE_INV : MODE_FWD, flag = (h.flag || fused) ? 1 : 0;
+    const SimEntry *e =
+        h.arith == ARITH_GOLD
+            ? find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge)
+        : h.arith == ARITH_SHOUP
+            ? find_arith_kernel_in_registry<ARITH_SHOUP, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge)
+            : find_kernel_in_registry<SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
     if (!e || e->f0 != h.f0 || e->logt != h.logt || (fused && h.kind != KIND_ROW)) {
       g_err = "registry mismatch";
       return PLAN_ERR_LOGIC;
@@ -79,6 +84,15 @@ int sim_transform(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t
                   uint64_t *dst, const uint64_t *src) {
   HostPlan pl;
   int rc = build_plan(pl, p, g, n, n0_log2, batch, inverse ? PLAN_INVERSE : PLAN_FORWARD, g_err);
+  if (rc) return rc;
+  return run_plan(pl, inverse != 0, dst, src);
+}
+
+// The same with extra plan flags (PLAN_GENERIC_ARITHMETIC, PLAN_FIXED_POINT: the arithmetic back end).
+int sim_transform_flags(uint64_t p, uint64_t g, uint64_t n, uint32_t n0_log2, uint64_t batch, int inverse,
+                        uint32_t flags, uint64_t *dst, const uint64_t *src) {
+  HostPlan pl;
+  int rc = build_plan(pl, p, g, n, n0_log2, batch, (inverse ? PLAN_INVERSE : PLAN_FORWARD) | flags, g_err);
   if (rc) return rc;
   return run_plan(pl, inverse != 0, dst, src);
 }

@@ -39,6 +39,8 @@ def load() -> ctypes.CDLL:
         L.sim_last_error.restype = ctypes.c_char_p
         L.sim_transform.restype = _int
         L.sim_transform.argtypes = [_u64, _u64, _u64, _u32, _u64, _int, _p64, _p64]
+        L.sim_transform_flags.restype = _int
+        L.sim_transform_flags.argtypes = [_u64, _u64, _u64, _u32, _u64, _int, _u32, _p64, _p64]
         L.sim_forward_multiply.restype = _int
         L.sim_forward_multiply.argtypes = [_u64, _u64, _u64, _u32, _u64, _p64, _p64, _p64]
         L.sim_sharded_columns.restype = _int
@@ -78,11 +80,12 @@ class SimError(ValueError):
 
 
 def transform(src: np.ndarray, p: int, g: int, n: int, n0_log2: int = 0, batch: int = 1,
-              inverse: bool = False) -> np.ndarray:
+              inverse: bool = False, flags: int = 0) -> np.ndarray:
+    """flags: extra plan flags (8 = generic arithmetic, 16 = FixedPoint64 back end)"""
     L = load()
     src = np.ascontiguousarray(src, dtype=np.uint64)
     dst = np.full_like(src, 0x5555555555555555)
-    rc = L.sim_transform(p, g, n, n0_log2, batch, int(inverse), _ptr(dst), _ptr(src))
+    rc = L.sim_transform_flags(p, g, n, n0_log2, batch, int(inverse), flags, _ptr(dst), _ptr(src))
     if rc != 0:
         raise SimError((rc, L.sim_last_error().decode()))
     return dst

@@ -239,6 +239,55 @@ def test_other_moduli(eng, port, N, g):
         assert np.array_equal(run_inverse(eng, want, m, N=N, g=g), src)
 
 
+@pytest.mark.parametrize("arith,N,g", [("auto", oracle.GOLDILOCKS_P, 7), ("generic", oracle.GOLDILOCKS_P, 7),
+                                       ("fixed_point", oracle.TEST62_P, 3), ("fixed_point", 0x7FFFFFFFF9000001, None),
+                                       ("fixed_point", 65537, 3)])
+@pytest.mark.parametrize("log2m,n0,batch", [(1, 0, 3), (4, 0, 1), (9, 0, 5), (12, 0, 2), (13, 0, 1), (14, 3, 1),
+                                            (16, 0, 1), (17, 8, 1), (20, 9, 1), (22, 0, 1)])
+def test_arithmetic_back_ends(eng, port, arith, N, g, log2m, n0, batch):
+    """the Goldilocks kernels (chosen automatically for
+    p = 2^64 - 2^32 + 1) and the FixedPoint64 (Shoup) kernels give the oracle's results bit for
+    bit, forward and inverse, on every tile family the planner reaches."""
+    if g is None:  # a 63-bit prime with 2^24 | p - 1 (the largest moduli the FixedPoint64 back end takes): find a generator of the 2-power subgroup
+        g = next(c for c in range(2, 200) if pow(c, (N - 1) // 2, N) == N - 1)
+    m = 1 << log2m
+    if (N - 1) % m:
+        pytest.skip("the field has no root of this order")
+    # (the oracle's splitmix fill rejects values >= N: hopeless for a 17-bit modulus)
+    src = (port.fill_splitmix(m * batch, 31 + log2m, N) if N >> 32 else
+           np.random.default_rng(log2m).integers(0, N, size=m * batch, dtype=np.uint64))
+    ntt = eng.NTT(eng.Modulus(N, g), m, n0_log2=n0, batch=batch, arithmetic=arith)
+    tag = {"auto": "[goldilocks]", "fixed_point": "[fixed-point]", "generic": ""}[arith]
+    assert ntt.describe().startswith(tag) and (tag or not ntt.describe().startswith("["))
+    d = dev(src)
+    ntt.compute_forward(d)
+    got = host(d)
+    for b in range(batch):
+        assert np.array_equal(got[b * m:(b + 1) * m], port.forward(src[b * m:(b + 1) * m], N, g)), (arith, b)
+    ntt.compute_inverse(d)
+    assert np.array_equal(host(d), src)
+
+
+def test_arithmetic_back_ends_extreme_values(eng, port):
+    """all-(p-1), all-zero and single-spike inputs through the special back ends"""
+    for arith, N, g in (("auto", oracle.GOLDILOCKS_P, 7), ("fixed_point", oracle.TEST62_P, 3)):
+        m = 1 << 13
+        ntt = eng.NTT(eng.Modulus(N, g), m, arithmetic=arith)
+        for src in (np.full(m, N - 1, dtype=np.uint64), np.zeros(m, dtype=np.uint64),
+                    np.concatenate([[N - 1], np.zeros(m - 1)]).astype(np.uint64),
+                    (np.arange(m, dtype=np.uint64) % np.uint64(2)) * np.uint64(N - 1)):
+            d = dev(src)
+            ntt.compute_forward(d)
+            assert np.array_equal(host(d), port.forward(src, N, g)), arith
+            ntt.compute_inverse(d)
+            assert np.array_equal(host(d), src)
+
+
+def test_fixed_point_needs_a_modulus_below_2p63(eng):
+    with pytest.raises(ValueError):  # SVENTT_ERR_INVALID_ARGUMENT
+        eng.NTT(eng.Modulus(P, G), 1 << 10, arithmetic="fixed_point")
+
+
 def test_edge_values(eng, port):
     for m in (2, 16, 1 << 12, 1 << 16):
         for src in (np.zeros(m, dtype=np.uint64), np.full(m, P - 1, dtype=np.uint64),
