@@ -30,8 +30,11 @@ template <class kernel_type> constexpr std::uint32_t requested_rows_log2(void) {
 // The plan for kernel_type with the given SVENTT_FORWARD/SVENTT_INVERSE flags.  A split the
 // engine's tiles do not cover (too few columns for the column pass, rows longer than a row
 // tile ...) is not an error of the caller's kernel_type: the engine then plans on its own.
-template <class kernel_type> sventt_plan *create_plan(const std::uint32_t flags) {
+template <class kernel_type> sventt_plan *create_plan(std::uint32_t flags) {
   using modulus_type = typename kernel_type::modulus_type;
+  if constexpr (kernel_type::uses_fixed_point()) {
+    flags |= SVENTT_FIXED_POINT;  // FixedPoint64SVE / FixedPoint64Scalar layers: the Shoup kernels
+  }
   sventt_plan *plan{};
   constexpr std::uint32_t rows_log2{requested_rows_log2<kernel_type>()};
   // the inverse divides by the product of the layers' inverse_factor arguments: 1 (no

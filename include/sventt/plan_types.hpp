@@ -35,13 +35,17 @@
 namespace sventt {
 
 // ---- modular multiplication back ends ---------------------------------------
-// All four select the engine's one device arithmetic (64-bit Montgomery with
-// canonical results, sve_ntt_amd/csrc/field64.h); the host-side conversions the
+// PAdic64* select the engine's Montgomery kernels (sve_ntt_amd/csrc/field64.h: ARITH_MONT; the
+// Goldilocks prime gets its own reduction automatically), FixedPoint64* its Shoup kernels
+// (ARITH_SHOUP: c = a*w - hi64(a*w')*N with w' stored beside each twiddle, the arithmetic of
+// modmul/sve/fixed-point-64.hpp:60-68 of the reference; modulus < 2^63).  Every back end returns
+// canonical residues, so the results do not depend on the choice.  The host-side conversions the
 // reference's callers use on data are kept.
 namespace detail {
 
-template <class modulus_type_> struct modmul_tag {
+template <class modulus_type_, bool fixed_point_ = false> struct modmul_tag {
   using modulus_type = modulus_type_;
+  static constexpr bool is_fixed_point{fixed_point_};
 
   // b * 2^64 mod N  (modmul/scalar/p-adic-64.hpp:16-19 of the reference)
   static constexpr std::uint64_t to_montgomery(const std::uint64_t b) {
@@ -68,8 +72,18 @@ constexpr bool is_power_of_two(const std::uint64_t x) { return std::has_single_b
 
 template <class modulus_type> class PAdic64SVE : public detail::modmul_tag<modulus_type> {};
 template <class modulus_type> class PAdic64Scalar : public detail::modmul_tag<modulus_type> {};
-template <class modulus_type> class FixedPoint64SVE : public detail::modmul_tag<modulus_type> {};
-template <class modulus_type> class FixedPoint64Scalar : public detail::modmul_tag<modulus_type> {};
+// FixedPoint64 keeps data and twiddles in the plain domain: its to/from_montgomery are the
+// identity (modmul/scalar/fixed-point-64.hpp:16-22 of the reference)
+template <class modulus_type> class FixedPoint64SVE : public detail::modmul_tag<modulus_type, true> {
+public:
+  static constexpr std::uint64_t to_montgomery(const std::uint64_t b) { return b; }
+  static constexpr std::uint64_t from_montgomery(const std::uint64_t b) { return b; }
+};
+template <class modulus_type> class FixedPoint64Scalar : public detail::modmul_tag<modulus_type, true> {
+public:
+  static constexpr std::uint64_t to_montgomery(const std::uint64_t b) { return b; }
+  static constexpr std::uint64_t from_montgomery(const std::uint64_t b) { return b; }
+};
 
 // ---- butterfly layers -------------------------------------------------------------
 // <modmul, m, n, inverse_factor = 1, store_precomputation = true>: `radix` fused
@@ -88,6 +102,7 @@ struct radix_layer {
   static constexpr std::uint64_t get_m(void) { return m; }
   static constexpr std::uint64_t get_n(void) { return n; }
   static constexpr std::uint64_t get_inverse_factor(void) { return inverse_factor; }
+  static constexpr bool uses_fixed_point(void) { return modmul_type::is_fixed_point; }
   static constexpr bool is_six_step_layer{false};
 };
 
@@ -121,6 +136,9 @@ template <class modmul_type_, std::uint64_t m, class inner_kernel_type_> struct 
   static constexpr std::uint64_t get_radix(void) { return inner_kernel_type::get_m(); }
   // a six-step layer has no inverse_factor of its own; its inner kernel's layers may
   static constexpr std::uint64_t get_inverse_factor(void) { return inner_kernel_type::get_inverse_factor(); }
+  static constexpr bool uses_fixed_point(void) {
+    return modmul_type::is_fixed_point || inner_kernel_type::uses_fixed_point();
+  }
   static constexpr bool is_six_step_layer{true};
   class buffer_type {};  // scratch lived here in the reference; the GPU passes need none
 };
@@ -221,6 +239,9 @@ public:
     ((f = modulus_type::multiply(f, layer_types::get_inverse_factor() % modulus_type::get_modulus())), ...);
     return f;
   }
+  // one plan runs one arithmetic: the FixedPoint64 kernels as soon as any layer names them (the
+  // reference's tests mix both per layer, tests/ntt-tests/iterative-scalar-radix8-two12.hpp:11-18)
+  static constexpr bool uses_fixed_point(void) { return (layer_types::uses_fixed_point() || ...); }
 };
 
 // RecursiveNTT<modulus, m, layer, inner_kernel, separate_twiddle>: one outer layer
@@ -260,6 +281,9 @@ public:
   static constexpr std::uint64_t get_inverse_factor(void) {
     return modulus_type::multiply(layer_type::get_inverse_factor() % modulus_type::get_modulus(),
                                   inner_kernel_type::get_inverse_factor());
+  }
+  static constexpr bool uses_fixed_point(void) {
+    return layer_type::uses_fixed_point() || inner_kernel_type::uses_fixed_point();
   }
 };
 

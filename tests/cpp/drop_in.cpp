@@ -86,6 +86,30 @@ using four_step =
                  row6, true>;
 } // namespace test62
 
+namespace fixed_point {
+// tests/ntt-tests/iterative-scalar-radix8-two12.hpp of the reference: PAdic64 and FixedPoint64
+// layers alternate; one FixedPoint64 layer selects the Shoup kernels for the plan
+using modulus_type = Modulus<UINT64_C(0x3a00000000000001), 3>;
+constexpr std::uint64_t m{std::uint64_t{1} << 12};
+using mixed_radix8 =
+    IterativeNTT<modulus_type, m, RadixEightScalarLayer<PAdic64Scalar<modulus_type>, m, (m >> 0)>,
+                 RadixEightScalarLayer<FixedPoint64Scalar<modulus_type>, m, (m >> 3)>,
+                 RadixEightScalarLayer<PAdic64Scalar<modulus_type>, m, (m >> 6)>,
+                 RadixEightScalarLayer<FixedPoint64Scalar<modulus_type>, m, (m >> 9), m>>;
+// a whole kernel on FixedPoint64SVE layers, six-step shaped, 2^20 points
+constexpr std::uint64_t n{std::uint64_t{1} << 20}, r{std::uint64_t{1} << 9}, c{std::uint64_t{1} << 11};
+using fp = FixedPoint64SVE<modulus_type>;
+using col = IterativeNTT<modulus_type, r, RadixEightSVELayer<fp, r, r>, RadixEightSVELayer<fp, r, (r >> 3)>,
+                         RadixEightSVELayer<fp, r, (r >> 6)>>;
+using row = IterativeNTT<modulus_type, c, RadixEightSVELayer<fp, c, c>, RadixEightSVELayer<fp, c, (c >> 3)>,
+                         RadixEightSVELayer<fp, c, (c >> 6)>, RadixFourSVELayer<fp, c, (c >> 9), n>>;
+using six_step = RecursiveNTT<modulus_type, n,
+                              GenericSVELayer<fp, n, col, 8, 2, TransposeParallelSVEInRegister<8, 8>>, row, true>;
+static_assert(mixed_radix8::uses_fixed_point() && six_step::uses_fixed_point());
+static_assert(!test62::iterative_radix8::uses_fixed_point());
+static_assert(FixedPoint64SVE<modulus_type>::to_montgomery(12345) == 12345);
+} // namespace fixed_point
+
 namespace big {
 // BASELINE config #3 spelled as a six-step 2^24 = 2^11 x 2^13
 using modulus_type = Modulus<UINT64_C(0xfffffc6e80000001), 3>;
@@ -300,6 +324,12 @@ int main(int argc, char **argv) {
   ok &= check<test62::recursive_radix248, true>("recursive, SVE, radix-2,4,8");
   ok &= check<test62::four_step, false>("recursive, SVE, four-step");
   ok &= check<test62::four_step, true>("recursive, SVE, four-step");
+  ok &= check<fixed_point::mixed_radix8, false>("iterative, scalar, radix-8, PAdic64/FixedPoint64 layers");
+  ok &= check<fixed_point::mixed_radix8, true>("iterative, scalar, radix-8, PAdic64/FixedPoint64 layers");
+  ok &= check<fixed_point::six_step, false>("six-step 2^20 on FixedPoint64SVE layers");
+  ok &= check<fixed_point::six_step, true>("six-step 2^20 on FixedPoint64SVE layers");
+  ok &= NTT<fixed_point::six_step>{}.describe().rfind("[fixed-point]", 0) == 0;
+  ok &= NTT<test62::four_step>{}.describe().rfind("[fixed-point]", 0) != 0;
   ok &= check<big::kernel_type, false>("six-step 2^24 = 2^11 x 2^13");
   ok &= check<big::kernel_type, true>("six-step 2^24 = 2^11 x 2^13");
   ok &= check_errors();
