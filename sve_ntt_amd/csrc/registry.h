@@ -29,11 +29,7 @@ template <> struct DefaultSteps<9> { using type = Steps<4, 4, 1>; };
 template <> struct DefaultSteps<10> { using type = Steps<4, 4, 2>; };
 template <> struct DefaultSteps<11> { using type = Steps<4, 4, 3>; };
 template <> struct DefaultSteps<12> { using type = Steps<4, 4, 4>; };
-#if defined(SVENTT_ROW13_1444)  // experiment: the short step first, so that the last step is a long one
-template <> struct DefaultSteps<13> { using type = Steps<1, 4, 4, 4>; };
-#else
 template <> struct DefaultSteps<13> { using type = Steps<4, 4, 4, 1>; };
-#endif
 
 // ROW tiles end on a short step where that helps: a last step of k stages leaves each thread
 // 2^k consecutive elements (8 * 2^k bytes), and a wave's store then touches 64 separate runs;

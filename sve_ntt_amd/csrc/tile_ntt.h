@@ -213,47 +213,6 @@ struct TileNTT {
     }
   }
 
-  // Persistent workgroups with an LDS-DMA prefetch (tile_launch.h: tile_kernel_dma): a tile whose
-  // elements are always in range (whole columns, or one whole row) and whose steps exchange
-  // through LDS.  The LDS image of a tile is dead from the moment the last step has read it; the
-  // NEXT tile of the workgroup is fetched into it with global_load_lds_dwordx4 (no VGPRs, 1 KiB
-  // per wave and instruction) while the last step computes and stores, and the next tile's first
-  // step reads its input from LDS instead of waiting for HBM.  This is the role of the
-  // reference's cache-resident block buffer (layer/sve/blocked-generic.hpp:139-154).
-#if defined(SVENTT_NO_STAGE_ASM)
-  static constexpr bool DMA_OK = false;  // the pipeline is part of the assembly path
-#else
-  static constexpr bool DMA_OK = LOGE == 4 && NSTEPS > 1 && LOGT >= 7 && (COL ? F0 >= 1 : LOGT == LOGL);
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__)
-  // Starts the fetch of tile `t` into lds[0 .. 2^LOGT) in tile-index order (linear, unswizzled):
-  // lane p of piece j brings elements I = 2 (j NT + tid) and I + 1 (16 bytes, same row).
-  // Written as assembly on purpose: a global_load_lds the compiler knows about makes it wait
-  // vmcnt(0) before every later LDS access of the function (it cannot tell which pending VMEM
-  // operation writes LDS), which serialises all twiddle loads.  Hidden from it, the fetch only
-  // makes the compiler's own vmcnt waits more conservative (the counter retires in order); the
-  // one consumer that needs the fetched data waits explicitly: dma_wait() below.
-  __device__ __forceinline__ static void dma_tile(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
-    constexpr int PIECES = (1 << LOGT) / (2 * NT);
-    const u32 lds_base = (u32)(size_t)(__attribute__((address_space(3))) char *)lds;
-#pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-      const u32 I = 2u * ((u32)j * NT + tid);
-      const u64 *g = a.src + saddr(a, t, I);
-      // M0 = LDS byte address of the wave's first lane; the hardware adds 16 * lane
-      const u32 m0 = __builtin_amdgcn_readfirstlane(lds_base + 16u * ((u32)j * NT + (tid & ~63u)));
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :
-                   : "v"(g), "s"(m0)
-                   : "m0", "memory");
-    }
-  }
-  // Called by the last step right before its stores to HBM (the fetch has had the step's
-  // butterflies to complete; no store is outstanding yet, so this never waits for one).
-  __device__ __forceinline__ static void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
-
 #if defined(SVENTT_STAGE_ASM)
   // first element of the b-th butterfly (ascending) of stage bit r over 16 registers
   static constexpr int bf_first(int r, int b) { return ((b >> r) << (r + 1)) | (b & ((1 << r) - 1)); }
@@ -351,12 +310,8 @@ struct TileNTT {
   // in source order between the (volatile) assembly statements, so everything that comes from
   // a table is requested one statement group ahead of its use.  SYNC: the step reads what the
   // previous step wrote to LDS; the barrier comes after the first twiddle requests.
-  // DMA: the persistent pipeline above -- the step that would read HBM reads the linear LDS
-  // image the previous iteration fetched, and the step that writes HBM starts the fetch of
-  // `next` (if any) as soon as every wave has read the old image.
-  template <int SI, bool SYNC, bool DMA = false>
-  __device__ __forceinline__ static void step_asm(const PassArgs &a, const Tile &t, u32 tid, u64 *lds,
-                                                  const Tile &next, bool has_next) {
+  template <int SI, bool SYNC>
+  __device__ __forceinline__ static void step_asm(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
     constexpr int k = STEPS::k[SI];
     constexpr int HI = LOGL - STEPS::sum(SI);
     constexpr int LO = HI - k;
@@ -383,14 +338,11 @@ struct TileNTT {
     // first stage's twiddles: requested ahead of the barrier and of the data
     const GroupTwiddles w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low);
     const GroupTwiddles w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low);
-    if constexpr (SYNC || (DMA && from_hbm)) __syncthreads();  // (DMA: also waits for the fetch)
+    if constexpr (SYNC) __syncthreads();
     // ---- gather ------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if constexpr (DMA && from_hbm) {
-#pragma unroll
-        for (int v = 0; v < R; ++v) x[g * R + v] = lds[I0[g] | ((u32)v << lo)];
-      } else if constexpr (from_hbm) {
+      if constexpr (from_hbm) {
         const u64 vstride = COL ? (a.src_istride << LO) : (1ull << lo);
         const u64 *p0 = a.src + saddr(a, t, I0[g]);
 #pragma unroll
@@ -405,11 +357,6 @@ struct TileNTT {
 #pragma unroll
         for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
       }
-    }
-    if constexpr (DMA && from_hbm && !to_hbm) __syncthreads();  // all reads before this step's writes
-    if constexpr (DMA && to_hbm) {
-      __syncthreads();  // every wave has read the image: it may be overwritten
-      if (has_next) dma_tile(a, next, tid, lds);
     }
     if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), c);
     // ---- k fused stages ------------------------------------------------------
@@ -427,9 +374,6 @@ struct TileNTT {
         const Operands o3 = epilogue_load<k, LO, 3>(a, t, I0);
         MontGroup<2>::run(x, o2.v[0], o2.v[1], o2.v[2], o2.v[3], c);
         MontGroup<3>::run(x, o3.v[0], o3.v[1], o3.v[2], o3.v[3], c);
-      }
-      if constexpr (DMA) {
-        if (has_next) dma_wait();  // this wave's share of the next tile's image is in LDS
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -530,20 +474,13 @@ struct TileNTT {
 
   // One step for one thread.  `first`/`last` say whether this step touches HBM.
   // SYNC (device only): a workgroup barrier separates this step from the previous one.
-  template <int SI, bool SYNC = false, bool DMA = false>
+  template <int SI, bool SYNC = false>
   F64_HD static void step(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
-    step<SI, SYNC, DMA>(a, t, tid, lds, t, false);
-  }
-  template <int SI, bool SYNC, bool DMA>
-  F64_HD static void step(const PassArgs &a, const Tile &t, u32 tid, u64 *lds, const Tile &next, bool has_next) {
 #if defined(SVENTT_STAGE_ASM)
     if constexpr (LOGE == 4) {
-      step_asm<SI, SYNC, DMA>(a, t, tid, lds, next, has_next);
+      step_asm<SI, SYNC>(a, t, tid, lds);
       return;
     }
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SVENTT_STAGE_ASM)
-    static_assert(!DMA, "the DMA pipeline exists for the assembly path only");
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (SYNC) __syncthreads();
