@@ -18,6 +18,10 @@ for P, G, log2n in ((0xFFFFFC6E80000001, 3, 31), (0xFFFFFFFF00000001, 7, 32)):
     step = 1 << 28
     for lo in range(0, m, step):  # (one torch.arange of 2^32 elements exceeds torch's own launch limits)
         buf[lo:lo + step] = torch.arange(S0 + lo, S0 + lo + step, dtype=torch.int64, device="cuda")
+    # one untimed round trip first: the first launch of each kernel loads its code object and sets its
+    # LDS attribute (r01 timed cold calls here and reported the inverse at twice the forward time)
+    ntt.compute_forward(buf)
+    ntt.compute_inverse(buf)
     torch.cuda.synchronize(); t1 = time.time()
     ntt.compute_forward(buf)
     torch.cuda.synchronize(); t2 = time.time()

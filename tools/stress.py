@@ -32,8 +32,13 @@ while time.time() < t_end:
     inverse = bool(rng.integers(2))
     in_place = bool(rng.integers(2))
     fused = (not inverse) and rng.random() < 0.25
+    # arithmetic back end: the plan's own choice, or forced (fixed_point needs p < 2^63)
+    arith = str(rng.choice(["auto", "auto", "generic", "fixed_point"]))
+    if arith == "fixed_point" and p >> 63:
+        arith = "generic"
+    divisor = int(rng.choice([0, 0, 1, 12345])) if inverse else 0
     try:
-        ntt = eng.NTT(eng.Modulus(p, g), n, n0_log2=n0, batch=batch)
+        ntt = eng.NTT(eng.Modulus(p, g), n, n0_log2=n0, batch=batch, arithmetic=arith, inverse_divisor=divisor)
     except ValueError:
         continue  # a split the tiles do not cover; the planner said so
     src = rng.integers(0, p, size=n * batch, dtype=np.uint64)
@@ -55,6 +60,9 @@ while time.time() < t_end:
     for b in range(batch):
         a = src[b * n:(b + 1) * n]
         want = port.inverse(a, p, g) if inverse else (port.forward(a, p, g) if n > 1 else a.copy())
+        if inverse and divisor:  # the oracle divides by n; the plan by `divisor`
+            factor = n * pow(divisor, -1, p) % p
+            want = np.array((want.astype(object) * factor) % p, dtype=np.uint64)
         if fused:
             want = np.array((want.astype(object) * op[b * n:(b + 1) * n].astype(object)) % p, dtype=np.uint64)
         if not np.array_equal(got[b * n:(b + 1) * n], want):
@@ -68,7 +76,7 @@ while time.time() < t_end:
     kinds[key] = kinds.get(key, 0) + 1
     if not ok:
         fails += 1
-        print(f"MISMATCH p={p:#x} g={g:#x} n=2^{log2n} n0={n0} batch={batch} inverse={inverse} "
+        print(f"MISMATCH p={p:#x} g={g:#x} n=2^{log2n} n0={n0} batch={batch} inverse={inverse} arith={arith} divisor={divisor} "
               f"in_place={in_place} fused={fused} plan=[{key}] batch_index={b}", flush=True)
 print(f"{cases} cases, {fails} mismatches, {len(kinds)} distinct plans, seed {seed}")
 sys.exit(1 if fails else 0)
