@@ -34,7 +34,18 @@ def needs_build() -> bool:
     return not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest_input()
 
 
+def regenerate_stage_asm() -> None:
+    """stage_asm.inc is generated (and committed); refresh it when its generator is newer."""
+    gen = os.path.join(CSRC, "gen_stage_asm.py")
+    inc = os.path.join(CSRC, "stage_asm.inc")
+    if not os.path.exists(inc) or os.path.getmtime(inc) < os.path.getmtime(gen):
+        text = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
+        with open(inc, "w") as f:
+            f.write(text)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    regenerate_stage_asm()
     if not force and not needs_build():
         return LIB
     objdir = os.path.join(HERE, "build")
