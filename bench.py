@@ -225,7 +225,8 @@ def main() -> None:
         step()
     # per-pass HIP events on every 4th step of the timed region (an event pair around every
     # launch costs 3-7 % of the step, tools/event_overhead.py; a quarter of them ~1 %)
-    sampled = [k for k in range(steps) if k % 4 == 0]
+    stride = 64 if args.config == "cfg2" else 4  # (a 10 us transform would mostly measure the events)
+    sampled = [k for k in range(steps) if k % stride == 0]
     events = {k: [torch.cuda.Event(enable_timing=True) for _ in range(npass + 1)] for k in sampled}
     barrier()
     t0 = time.perf_counter()
