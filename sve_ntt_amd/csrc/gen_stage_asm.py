@@ -42,7 +42,9 @@ class Slot:
 
 
 def zero_ext_init(S):
-    return ['v_mov_b32 v%d, 0' % (S.z + 1)]
+    """The high half of the slot's zero-extension pair stays 0 for the whole step: it is an
+    in/out operand ("+{v41}"(zr[0]) ...) that no instruction writes, so nothing to do here."""
+    return []
 
 
 def mont(S, al, ah, w0, w1):
@@ -288,7 +290,8 @@ CONSTS = {
 
 def clobbers(W):
     cl = ['"vcc"', '"scc"']
-    cl += ['"v%d"' % r for r in range(TEMP_BASE, TEMP_BASE + TEMP_PER_SLOT * W)]
+    zeros = {Slot(k).z + 1 for k in range(W)}
+    cl += ['"v%d"' % r for r in range(TEMP_BASE, TEMP_BASE + TEMP_PER_SLOT * W) if r not in zeros]
     cl += ['"s%d"' % r for r in range(SG_BASE, SG_BASE + 4 * W)]
     return ', '.join(cl)
 
@@ -298,6 +301,8 @@ def asm_stmt(streams, data_regs, inputs):
     text = ''.join('        "%s\\n\\t"\n' % l for l in body)
     used = [k for k in CONSTS if any('%%[%s]' % k in l for l in body)]
     outs = ', '.join('"+{v[%d:%d]}"(x[%d])' % (2 * i, 2 * i + 1, i) for i in data_regs)
+    # the slots' persistent zeros (high halves of the zero-extension pairs)
+    outs += ''.join(', "+{v%d}"(zr[%d])' % (Slot(k).z + 1, k) for k in range(len(streams)))
     return ('    asm volatile(\n%s        : %s\n        : %s\n        : %s);\n'
             % (text, outs, ', '.join(inputs + [CONSTS[k] for k in used]), clobbers(len(streams))))
 
@@ -333,7 +338,8 @@ def gen_bfly_group(arith, mode, r, grp, triv):
         streams.append(fn(arith, S, 2 * a, 2 * b, W))
     s = 'template <> struct BflyGroup<%s, %s, %d, %d, %s> {\n' % (arith, mode, r, grp, 'true' if triv else 'false')
     s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 w0, u64 w1, u64 w2, u64 w3,\n'
-          '                                             u64 p0, u64 p1, u64 p2, u64 p3, const AsmConsts &c) {\n')
+          '                                             u64 p0, u64 p1, u64 p2, u64 p3, u32 (&zr)[4],\n'
+          '                                             const AsmConsts &c) {\n')
     s += asm_stmt(streams, sorted(regs), inputs)
     s += '  }\n};\n'
     return s
@@ -358,7 +364,7 @@ def gen_twist_group(arith, grp):
         streams.append(twist_a(arith, Slot(k), 2 * (tw * grp + k), H, L))
     s = 'template <> struct TwistGroup<%s, %d> {\n' % (arith, grp)
     s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], const u64 (&h)[%d], const u64 (&l)[%d],\n'
-          '                                             const u64 (&hp)[%d], const u64 (&lp)[%d],\n'
+          '                                             const u64 (&hp)[%d], const u64 (&lp)[%d], u32 (&zr)[4],\n'
           '                                             const AsmConsts &c) {\n' % (tw, tw, tw, tw))
     s += asm_stmt(streams, range(tw * grp, tw * grp + tw), inputs)
     s += '  }\n};\n'
@@ -372,7 +378,7 @@ def gen_mont_group(grp):
         inputs += halves('w%d' % k, 'w%d' % k)
     s = 'template <> struct MontGroup<%d> {\n' % grp
     s += ('  static __device__ __forceinline__ void run(u64 (&x)[16], u64 w0, u64 w1, u64 w2, u64 w3,\n'
-          '                                             const AsmConsts &c) {\n')
+          '                                             u32 (&zr)[4], const AsmConsts &c) {\n')
     s += asm_stmt(streams, range(4 * grp, 4 * grp + 4), inputs)
     s += '  }\n};\n'
     return s
@@ -383,7 +389,7 @@ def gen_scale_group(r, grp):
     bfs = butterflies(r)[4 * grp:4 * grp + 4]
     streams = [mul_inplace(Slot(k), 2 * a, '%[s0]', '%[s1]') for k, (a, _) in enumerate(bfs)]
     s = 'template <> struct ScaleGroup<%d, %d> {\n' % (r, grp)
-    s += '  static __device__ __forceinline__ void run(u64 (&x)[16], u64 s, const AsmConsts &c) {\n'
+    s += '  static __device__ __forceinline__ void run(u64 (&x)[16], u64 s, u32 (&zr)[4], const AsmConsts &c) {\n'
     s += asm_stmt(streams, [a for a, _ in bfs], ['[s0] "s"((u32)s)', '[s1] "s"((u32)(s >> 32))'])
     s += '  }\n};\n'
     return s
@@ -402,6 +408,8 @@ struct AsmConsts {
   u32 nn0, nn1;  // the words of negN = 2^64 - N (Goldilocks: nn0 = eps = 2^32 - 1)
 };
 
+// zr: four words that hold 0 and live in v41/v53/v65/v77 (the high halves of the slots'
+// zero-extension pairs) -- operands of every group so that the compiler keeps them there.
 // four butterflies (x_a, x_a + 2^R) of stage bit R: the GRP-th four in ascending a, in the
 // arithmetic back end ARITH (field64.h); w_k / p_k: twiddle of the k-th and, for ARITH_SHOUP,
 // its precomputed companion.  TRIV: the stage's twiddles with (a mod 2^R) == 0 are omega^0

@@ -247,43 +247,44 @@ struct TileNTT {
   }
   // x[4 GRP + q] *= h[q] * l[q]   (twist_lookup + montmul of the C++ path, one assembly group)
   template <int GRP>
-  __device__ __forceinline__ static void twist_apply(u64 (&x)[E], const TwistFactors &f, const AsmConsts &c) {
+  __device__ __forceinline__ static void twist_apply(u64 (&x)[E], const TwistFactors &f, u32 (&zr)[4],
+                                                     const AsmConsts &c) {
     if constexpr (ARITH == ARITH_SHOUP)
-      TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.hp, f.lp, c);
+      TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.hp, f.lp, zr, c);
     else
-      TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.h, f.l, c);  // no companions: the arrays are ignored
+      TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.h, f.l, zr, c);  // no companions: the arrays are ignored
   }
   // all 16 elements; the factors of group g + 1 are requested before group g's ~230 VALU
   // instructions run.  `f0` holds group 0's, requested by the caller.
   template <int k, int LO>
   __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                    const u32 (&I0)[E >> k], const TwistFactors &f0,
-                                                   const AsmConsts &c) {
+                                                   u32 (&zr)[4], const AsmConsts &c) {
     if constexpr (ARITH == ARITH_SHOUP) {
       // four words per element: two elements per statement, the next pair requested ahead
       const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
-      twist_apply<0>(x, f0, c);
+      twist_apply<0>(x, f0, zr, c);
       const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
-      twist_apply<1>(x, f1, c);
+      twist_apply<1>(x, f1, zr, c);
       const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
-      twist_apply<2>(x, f2, c);
+      twist_apply<2>(x, f2, zr, c);
       const TwistFactors f4 = twist_load<k, LO, 4>(a, t, I0);
-      twist_apply<3>(x, f3, c);
+      twist_apply<3>(x, f3, zr, c);
       const TwistFactors f5 = twist_load<k, LO, 5>(a, t, I0);
-      twist_apply<4>(x, f4, c);
+      twist_apply<4>(x, f4, zr, c);
       const TwistFactors f6 = twist_load<k, LO, 6>(a, t, I0);
-      twist_apply<5>(x, f5, c);
+      twist_apply<5>(x, f5, zr, c);
       const TwistFactors f7 = twist_load<k, LO, 7>(a, t, I0);
-      twist_apply<6>(x, f6, c);
-      twist_apply<7>(x, f7, c);
+      twist_apply<6>(x, f6, zr, c);
+      twist_apply<7>(x, f7, zr, c);
     } else {
       const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
-      twist_apply<0>(x, f0, c);
+      twist_apply<0>(x, f0, zr, c);
       const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
-      twist_apply<1>(x, f1, c);
+      twist_apply<1>(x, f1, zr, c);
       const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
-      twist_apply<2>(x, f2, c);
-      twist_apply<3>(x, f3, c);
+      twist_apply<2>(x, f2, zr, c);
+      twist_apply<3>(x, f3, zr, c);
     }
   }
 
@@ -327,6 +328,7 @@ struct TileNTT {
     const AsmConsts c{a.f.N, a.f.negN, (u32)a.f.N, (u32)(a.f.N >> 32), (u32)a.f.Ninv,
                       (u32)(a.f.Ninv >> 32), __builtin_amdgcn_read_exec(), (u32)a.f.negN,
                       (u32)(a.f.negN >> 32)};
+    u32 zr[4] = {0u, 0u, 0u, 0u};  // the slots' zero-extension high halves (stage_asm.inc)
     u64 x[E];
     u32 I0[G], s_low[G];
 #pragma unroll
@@ -358,22 +360,22 @@ struct TileNTT {
         for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
       }
     }
-    if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), c);
+    if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), zr, c);
     // ---- k fused stages ------------------------------------------------------
     TwistFactors f0;
     Operands o0;
-    stages_asm<k, LO, lo, 0, twist_out, multiply_out>(a, t, x, I0, s_low, w0, w1, f0, o0, c);
+    stages_asm<k, LO, lo, 0, twist_out, multiply_out>(a, t, x, I0, s_low, w0, w1, f0, o0, zr, c);
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
-      if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, c);
+      if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, zr, c);
       if constexpr (multiply_out) {
         const Operands o1 = epilogue_load<k, LO, 1>(a, t, I0);
-        MontGroup<0>::run(x, o0.v[0], o0.v[1], o0.v[2], o0.v[3], c);
+        MontGroup<0>::run(x, o0.v[0], o0.v[1], o0.v[2], o0.v[3], zr, c);
         const Operands o2 = epilogue_load<k, LO, 2>(a, t, I0);
-        MontGroup<1>::run(x, o1.v[0], o1.v[1], o1.v[2], o1.v[3], c);
+        MontGroup<1>::run(x, o1.v[0], o1.v[1], o1.v[2], o1.v[3], zr, c);
         const Operands o3 = epilogue_load<k, LO, 3>(a, t, I0);
-        MontGroup<2>::run(x, o2.v[0], o2.v[1], o2.v[2], o2.v[3], c);
-        MontGroup<3>::run(x, o3.v[0], o3.v[1], o3.v[2], o3.v[3], c);
+        MontGroup<2>::run(x, o2.v[0], o2.v[1], o2.v[2], o2.v[3], zr, c);
+        MontGroup<3>::run(x, o3.v[0], o3.v[1], o3.v[2], o3.v[3], zr, c);
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -449,26 +451,27 @@ struct TileNTT {
   __device__ __forceinline__ static void stages_asm(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                     const u32 (&I0)[E >> k], const u32 (&s_low)[E >> k],
                                                     const GroupTwiddles &w0, const GroupTwiddles &w1,
-                                                    TwistFactors &f0, Operands &o0, const AsmConsts &c) {
+                                                    TwistFactors &f0, Operands &o0, u32 (&zr)[4],
+                                                    const AsmConsts &c) {
     constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
     constexpr int ps = LO + r;
     constexpr bool triv = stage_has_unit_twiddles<LO, ps>();
     constexpr bool more = rr + 1 < k;
     if constexpr (!COL && FLAG && MODE == MODE_INV && ps == LOGL - 1) {
       // fold 1/L into the top stage: (c*x0) +- (c*w)*x1, the table holds c*w
-      ScaleGroup<r, 0>::run(x, a.scale, c);
-      ScaleGroup<r, 1>::run(x, a.scale, c);
+      ScaleGroup<r, 0>::run(x, a.scale, zr, c);
+      ScaleGroup<r, 1>::run(x, a.scale, zr, c);
     }
     GroupTwiddles n0, n1;
     if constexpr (more) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low);
     BflyGroup<ARITH, MODE, r, 0, triv>::run(x, w0.w[0], w0.w[1], w0.w[2], w0.w[3], w0.p[0], w0.p[1], w0.p[2],
-                                            w0.p[3], c);
+                                            w0.p[3], zr, c);
     if constexpr (more) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low);
     if constexpr (!more && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
     if constexpr (!more && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
     BflyGroup<ARITH, MODE, r, 1, triv>::run(x, w1.w[0], w1.w[1], w1.w[2], w1.w[3], w1.p[0], w1.p[1], w1.p[2],
-                                            w1.p[3], c);
-    if constexpr (more) stages_asm<k, LO, lo, rr + 1, TW, MUL>(a, t, x, I0, s_low, n0, n1, f0, o0, c);
+                                            w1.p[3], zr, c);
+    if constexpr (more) stages_asm<k, LO, lo, rr + 1, TW, MUL>(a, t, x, I0, s_low, n0, n1, f0, o0, zr, c);
   }
 #endif  // SVENTT_STAGE_ASM
 
