@@ -42,6 +42,9 @@ enum : int { MODE_FWD = 0, MODE_INV = 1 };
 // (gen_stage_asm.py: same arithmetic as field64.h, conditional +N under an EXEC mask).
 // -DSVENTT_NO_STAGE_ASM keeps hipcc's code for A/B measurements; the host replay
 // (tests/cpu_sim) always runs the C++ below.
+#ifndef SVENTT_EARLY_STORES
+#define SVENTT_EARLY_STORES 1  // 0: A/B builds that store a thread's 16 outputs together at the end
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SVENTT_NO_STAGE_ASM)
 #define SVENTT_STAGE_ASM 1
 #include "stage_asm.inc"
@@ -256,7 +259,39 @@ struct TileNTT {
   }
   // all 16 elements; the factors of group g + 1 are requested before group g's ~230 VALU
   // instructions run.  `f0` holds group 0's, requested by the caller.
-  template <int k, int LO>
+  // x[FIRST .. FIRST + COUNT) to HBM (elements of a step that writes the pass's output).
+  // Neighbouring elements of a lowest step (lo == 0) leave as one 16-byte store.  Every address
+  // goes through an empty asm: hipcc's machine scheduler crashes (roc-7.2.0, SIGSEGV) when it
+  // tries to cluster plain stores across the assembly statements they are interleaved with.
+  template <int k, int LO, int FIRST, int COUNT>
+  __device__ __forceinline__ static void store_range(const PassArgs &a, const Tile &t, const u64 (&x)[E],
+                                                     const u32 (&I0)[E >> k]) {
+    constexpr int R = 1 << k, lo = F0 + LO;
+    constexpr bool pairs = !COL && lo == 0 && (FIRST % 2 == 0) && (COUNT % 2 == 0) && in_range_is_static();
+    const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
+#pragma unroll
+    for (int i = FIRST; i < FIRST + COUNT; i += (pairs ? 2 : 1)) {
+      const int g = i >> k, v = i & (R - 1);
+      u64 *p = a.dst + gaddr(a, t, I0[g]) + (u64)v * vstride;
+      asm volatile("" : "+v"(p));
+#if defined(SVENTT_STUB_HBM) || defined(SVENTT_STUB_STORES)
+      if (x[i] == 0x123456789abcdefull) *p = x[i];
+#else
+      if constexpr (pairs) {
+        ulonglong2 two;
+        two.x = x[i], two.y = x[i + 1];
+        *reinterpret_cast<ulonglong2 *>(p) = two;
+      } else {
+        if (in_range(a, t, I0[g] | ((u32)v << lo))) *p = x[i];
+      }
+#endif
+    }
+  }
+  static constexpr bool in_range_is_static() { return COL || LOGT == LOGL; }
+
+  // STORE (not used by the shipped tiles, see step_asm): the pass's output leaves right after its
+  // group's factors are applied
+  template <int k, int LO, bool STORE = false>
   __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                    const u32 (&I0)[E >> k], const TwistFactors &f0,
                                                    u32 (&zr)[4], const AsmConsts &c) {
@@ -264,27 +299,39 @@ struct TileNTT {
       // four words per element: two elements per statement, the next pair requested ahead
       const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
       twist_apply<0>(x, f0, zr, c);
+      if constexpr (STORE) store_range<k, LO, 0, 2>(a, t, x, I0);
       const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
       twist_apply<1>(x, f1, zr, c);
+      if constexpr (STORE) store_range<k, LO, 2, 2>(a, t, x, I0);
       const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
       twist_apply<2>(x, f2, zr, c);
+      if constexpr (STORE) store_range<k, LO, 4, 2>(a, t, x, I0);
       const TwistFactors f4 = twist_load<k, LO, 4>(a, t, I0);
       twist_apply<3>(x, f3, zr, c);
+      if constexpr (STORE) store_range<k, LO, 6, 2>(a, t, x, I0);
       const TwistFactors f5 = twist_load<k, LO, 5>(a, t, I0);
       twist_apply<4>(x, f4, zr, c);
+      if constexpr (STORE) store_range<k, LO, 8, 2>(a, t, x, I0);
       const TwistFactors f6 = twist_load<k, LO, 6>(a, t, I0);
       twist_apply<5>(x, f5, zr, c);
+      if constexpr (STORE) store_range<k, LO, 10, 2>(a, t, x, I0);
       const TwistFactors f7 = twist_load<k, LO, 7>(a, t, I0);
       twist_apply<6>(x, f6, zr, c);
+      if constexpr (STORE) store_range<k, LO, 12, 2>(a, t, x, I0);
       twist_apply<7>(x, f7, zr, c);
+      if constexpr (STORE) store_range<k, LO, 14, 2>(a, t, x, I0);
     } else {
       const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
       twist_apply<0>(x, f0, zr, c);
+      if constexpr (STORE) store_range<k, LO, 0, 4>(a, t, x, I0);
       const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
       twist_apply<1>(x, f1, zr, c);
+      if constexpr (STORE) store_range<k, LO, 4, 4>(a, t, x, I0);
       const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
       twist_apply<2>(x, f2, zr, c);
+      if constexpr (STORE) store_range<k, LO, 8, 4>(a, t, x, I0);
       twist_apply<3>(x, f3, zr, c);
+      if constexpr (STORE) store_range<k, LO, 12, 4>(a, t, x, I0);
     }
   }
 
@@ -349,7 +396,7 @@ struct TileNTT {
         const u64 *p0 = a.src + saddr(a, t, I0[g]);
 #pragma unroll
         for (int v = 0; v < R; ++v)
-#if defined(SVENTT_STUB_HBM)  // analysis builds only (tools/build_variant.sh stub): no HBM access
+#if defined(SVENTT_STUB_HBM) || defined(SVENTT_STUB_LOADS)  // analysis builds only (tools/build_variant.sh)
           x[g * R + v] = (u64)(uintptr_t)(p0 + (u64)v * vstride) >> 1;
 #else
           x[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
@@ -364,7 +411,15 @@ struct TileNTT {
     // ---- k fused stages ------------------------------------------------------
     TwistFactors f0;
     Operands o0;
-    stages_asm<k, LO, lo, 0, twist_out, multiply_out>(a, t, x, I0, s_low, w0, w1, f0, o0, zr, c);
+    // A wave cannot retire before its stores are acknowledged (s_endpgm waits for vmcnt = 0) and the
+    // workgroup's LDS is not free before its last wave retires (a build without the stores runs
+    // 10-15 % faster).  Storing each element as soon as it is final leaves only the last few stores
+    // in flight at the end.
+    // Measured (profiles/r02/asm_stages_ab.txt): it pays for the inverse column pass (-4 %), whose last
+    // stage is a full butterfly stage; the forward passes end on a twist or a short stage and lose
+    // more to the unmerged stores than they gain, so they keep storing at the end.
+    constexpr bool early = SVENTT_EARLY_STORES != 0 && to_hbm && COL && MODE == MODE_INV;
+    stages_asm<k, LO, lo, 0, twist_out, multiply_out, early>(a, t, x, I0, s_low, w0, w1, f0, o0, zr, c);
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
       if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, zr, c);
@@ -377,17 +432,19 @@ struct TileNTT {
         MontGroup<2>::run(x, o2.v[0], o2.v[1], o2.v[2], o2.v[3], zr, c);
         MontGroup<3>::run(x, o3.v[0], o3.v[1], o3.v[2], o3.v[3], zr, c);
       }
+      if constexpr (!early) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
-        u64 *p0 = a.dst + gaddr(a, t, I0[g]);
+        for (int g = 0; g < G; ++g) {
+          const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
+          u64 *p0 = a.dst + gaddr(a, t, I0[g]);
 #pragma unroll
-        for (int v = 0; v < R; ++v)
-#if defined(SVENTT_STUB_HBM)
-          if (x[g * R + v] == 0x123456789abcdefull) p0[(u64)v * vstride] = x[g * R + v];
+          for (int v = 0; v < R; ++v)
+#if defined(SVENTT_STUB_HBM) || defined(SVENTT_STUB_STORES)
+            if (x[g * R + v] == 0x123456789abcdefull) p0[(u64)v * vstride] = x[g * R + v];
 #else
-          if (in_range(a, t, I0[g] | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
+            if (in_range(a, t, I0[g] | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
 #endif
+        }
       }
     } else {
 #pragma unroll
@@ -441,13 +498,29 @@ struct TileNTT {
     return tw;
   }
 
+  // the eight elements of the GRP-th four butterflies of stage bit r, to HBM
+  template <int k, int LO, int r, int GRP>
+  __device__ __forceinline__ static void store_group(const PassArgs &a, const Tile &t, const u64 (&x)[E],
+                                                     const u32 (&I0)[E >> k]) {
+    constexpr int i0 = bf_first(r, 4 * GRP), i1 = bf_first(r, 4 * GRP + 1), i2 = bf_first(r, 4 * GRP + 2),
+                  i3 = bf_first(r, 4 * GRP + 3), h = 1 << r;
+    store_range<k, LO, i0, 1>(a, t, x, I0);
+    store_range<k, LO, i0 + h, 1>(a, t, x, I0);
+    store_range<k, LO, i1, 1>(a, t, x, I0);
+    store_range<k, LO, i1 + h, 1>(a, t, x, I0);
+    store_range<k, LO, i2, 1>(a, t, x, I0);
+    store_range<k, LO, i2 + h, 1>(a, t, x, I0);
+    store_range<k, LO, i3, 1>(a, t, x, I0);
+    store_range<k, LO, i3 + h, 1>(a, t, x, I0);
+  }
+
   // Stage rr of the step: two assembly groups of four butterflies.  Each group's twiddles were
   // requested a full stage earlier (w0 / w1 on entry): the same group of the NEXT stage is
   // requested right before this stage's group runs, so its L2 latency hides behind ~300 VALU
   // instructions per thread while three groups' worth of twiddle registers are live (24, not 32).
   // Ahead of the step's last group the first quarter of what the scatter multiplies by is
   // requested too (TW: twist factors into f0, MUL: operands of the fused product into o0).
-  template <int k, int LO, int lo, int rr, bool TW, bool MUL>
+  template <int k, int LO, int lo, int rr, bool TW, bool MUL, bool SCATTER = false>
   __device__ __forceinline__ static void stages_asm(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                     const u32 (&I0)[E >> k], const u32 (&s_low)[E >> k],
                                                     const GroupTwiddles &w0, const GroupTwiddles &w1,
@@ -469,9 +542,12 @@ struct TileNTT {
     if constexpr (more) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low);
     if constexpr (!more && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
     if constexpr (!more && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
+    if constexpr (!more && SCATTER) store_group<k, LO, r, 0>(a, t, x, I0);  // final: out they go
     BflyGroup<ARITH, MODE, r, 1, triv>::run(x, w1.w[0], w1.w[1], w1.w[2], w1.w[3], w1.p[0], w1.p[1], w1.p[2],
                                             w1.p[3], zr, c);
-    if constexpr (more) stages_asm<k, LO, lo, rr + 1, TW, MUL>(a, t, x, I0, s_low, n0, n1, f0, o0, zr, c);
+    if constexpr (!more && SCATTER) store_group<k, LO, r, 1>(a, t, x, I0);
+    if constexpr (more)
+      stages_asm<k, LO, lo, rr + 1, TW, MUL, SCATTER>(a, t, x, I0, s_low, n0, n1, f0, o0, zr, c);
   }
 #endif  // SVENTT_STAGE_ASM
 
