@@ -248,7 +248,7 @@ struct TileNTT {
     }
     return f;
   }
-  // x[4 GRP + q] *= h[q] * l[q]   (twist_lookup + montmul of the C++ path, one assembly group)
+  // x[TWG GRP + q] *= h[q] * l[q]   (twist_apply_cxx of the C++ path, one assembly group)
   template <int GRP>
   __device__ __forceinline__ static void twist_apply(u64 (&x)[E], const TwistFactors &f, u32 (&zr)[4],
                                                      const AsmConsts &c) {
@@ -257,8 +257,6 @@ struct TileNTT {
     else
       TwistGroup<ARITH, GRP>::run(x, f.h, f.l, f.h, f.l, zr, c);  // no companions: the arrays are ignored
   }
-  // all 16 elements; the factors of group g + 1 are requested before group g's ~230 VALU
-  // instructions run.  `f0` holds group 0's, requested by the caller.
   // x[FIRST .. FIRST + COUNT) to HBM (elements of a step that writes the pass's output).
   // Neighbouring elements of a lowest step (lo == 0) leave as one 16-byte store.  Every address
   // goes through an empty asm: hipcc's machine scheduler crashes (roc-7.2.0, SIGSEGV) when it
@@ -289,9 +287,9 @@ struct TileNTT {
   }
   static constexpr bool in_range_is_static() { return COL || LOGT == LOGL; }
 
-  // STORE (not used by the shipped tiles, see step_asm): the pass's output leaves right after its
-  // group's factors are applied
-  template <int k, int LO, bool STORE = false>
+  // The twist of all 16 elements; the factors of group g + 1 are requested before group g's ~230
+  // VALU instructions run.  `f0` holds group 0's, requested by the caller.
+  template <int k, int LO>
   __device__ __forceinline__ static void twist_all(const PassArgs &a, const Tile &t, u64 (&x)[E],
                                                    const u32 (&I0)[E >> k], const TwistFactors &f0,
                                                    u32 (&zr)[4], const AsmConsts &c) {
@@ -299,39 +297,27 @@ struct TileNTT {
       // four words per element: two elements per statement, the next pair requested ahead
       const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
       twist_apply<0>(x, f0, zr, c);
-      if constexpr (STORE) store_range<k, LO, 0, 2>(a, t, x, I0);
       const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
       twist_apply<1>(x, f1, zr, c);
-      if constexpr (STORE) store_range<k, LO, 2, 2>(a, t, x, I0);
       const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
       twist_apply<2>(x, f2, zr, c);
-      if constexpr (STORE) store_range<k, LO, 4, 2>(a, t, x, I0);
       const TwistFactors f4 = twist_load<k, LO, 4>(a, t, I0);
       twist_apply<3>(x, f3, zr, c);
-      if constexpr (STORE) store_range<k, LO, 6, 2>(a, t, x, I0);
       const TwistFactors f5 = twist_load<k, LO, 5>(a, t, I0);
       twist_apply<4>(x, f4, zr, c);
-      if constexpr (STORE) store_range<k, LO, 8, 2>(a, t, x, I0);
       const TwistFactors f6 = twist_load<k, LO, 6>(a, t, I0);
       twist_apply<5>(x, f5, zr, c);
-      if constexpr (STORE) store_range<k, LO, 10, 2>(a, t, x, I0);
       const TwistFactors f7 = twist_load<k, LO, 7>(a, t, I0);
       twist_apply<6>(x, f6, zr, c);
-      if constexpr (STORE) store_range<k, LO, 12, 2>(a, t, x, I0);
       twist_apply<7>(x, f7, zr, c);
-      if constexpr (STORE) store_range<k, LO, 14, 2>(a, t, x, I0);
     } else {
       const TwistFactors f1 = twist_load<k, LO, 1>(a, t, I0);
       twist_apply<0>(x, f0, zr, c);
-      if constexpr (STORE) store_range<k, LO, 0, 4>(a, t, x, I0);
       const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
       twist_apply<1>(x, f1, zr, c);
-      if constexpr (STORE) store_range<k, LO, 4, 4>(a, t, x, I0);
       const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
       twist_apply<2>(x, f2, zr, c);
-      if constexpr (STORE) store_range<k, LO, 8, 4>(a, t, x, I0);
       twist_apply<3>(x, f3, zr, c);
-      if constexpr (STORE) store_range<k, LO, 12, 4>(a, t, x, I0);
     }
   }
 
@@ -456,8 +442,6 @@ struct TileNTT {
     }
   }
 
-  // twiddles of the eight butterflies of stage rr of the step (forward walks the stage bits
-  // downwards, inverse upwards); omega^0 entries of a lowest step are not loaded
   // A lowest step's twiddles with index 0 are omega^0 and their butterflies multiply by nothing
   // -- unless the stage is the top stage of an inverse ROW pass that folds 1/L, whose table
   // holds (1/L) * omega^j (transforms of 2 and 4 points have both in one step).
