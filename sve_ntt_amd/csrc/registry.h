@@ -106,7 +106,16 @@ template <class Status, class Stream> struct KernelEntryT {
   int kind, logl, dir, flag;
   int logt, f0, threads, loge;
   Status (*launch)(const PassArgs &, u32 grid, Stream);
+  bool (*set_mapping_ok)();  // TileNTT::verify_set_mapping (host-side check, test tier)
+  int group_barriers;        // workgroup barriers per tile (the other exchanges are wave-local)
 };
+
+template <class TN, int SI = 0> constexpr int count_group_barriers() {
+  if constexpr (SI == TN::NSTEPS)
+    return 0;
+  else
+    return (TN::template sync_before<SI>() == TN::SYNC_GROUP ? 1 : 0) + count_group_barriers<TN, SI + 1>();
+}
 
 template <class TN, class Entry, template <class> class Launcher>
 Entry make_entry(int kind, int dir, int flag) {
@@ -120,6 +129,12 @@ Entry make_entry(int kind, int dir, int flag) {
   e.threads = TN::NT;
   e.loge = TN::LOGE;
   e.launch = &Launcher<TN>::launch;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  e.set_mapping_ok = &TN::template verify_set_mapping<0>;
+#else
+  e.set_mapping_ok = nullptr;
+#endif
+  e.group_barriers = count_group_barriers<TN>();
   return e;
 }
 

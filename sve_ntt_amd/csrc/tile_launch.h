@@ -20,7 +20,7 @@ template <class TN, int IDX>
 __device__ __forceinline__ void run_steps(const PassArgs &a, const typename TN::Tile &t, u32 tid,
                                           u64 *lds) {
   constexpr int SI = (TN::MODE == MODE_FWD) ? IDX : TN::NSTEPS - 1 - IDX;
-  TN::template step<SI, (IDX > 0)>(a, t, tid, lds);
+  TN::template step<SI, (IDX > 0 ? TN::template sync_before<SI>() : TN::SYNC_NONE)>(a, t, tid, lds);
   if constexpr (IDX + 1 < TN::NSTEPS) run_steps<TN, IDX + 1>(a, t, tid, lds);
 }
 

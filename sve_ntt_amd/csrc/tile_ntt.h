@@ -134,6 +134,72 @@ struct TileNTT {
   static_assert(LOGT >= LOGE && F0 + LOGL <= LOGT, "tile too small");
   static_assert(!COL || F0 + LOGL == LOGT, "a COL tile holds whole columns");
 
+  // ---- which thread holds which radix set ----------------------------------------------
+  // Set number s (LOGT - k bits) names the 2^k elements I = ((s >> lo) << hi) | (v << lo) |
+  // (s mod 2^lo).  Wave w of the workgroup owns the contiguous CHUNK [w, w + 1) * 2^(LOGT - WB)
+  // of the tile.  A step whose register bits [lo, hi) lie below the chunk bits is
+  // chunk-preserving: with s = w : g : lane (wave, set of the thread, lane) every wave then holds
+  // exactly its chunk, as it did in the neighbouring chunk-preserving steps -- the LDS exchange
+  // between two such steps stays inside each wave's own region and needs no workgroup barrier
+  // (2^13 rows: one barrier per tile instead of three; the waves of a workgroup drift apart and
+  // overlap each other's memory phases).  Other steps use s = tid + g * NT.
+  static constexpr int WB = (NT > 64) ? LOGT - LOGE - 6 : 0;  // log2(waves per workgroup)
+  template <int SI> static constexpr bool chunk_preserving() {
+    return NT <= 64 || (F0 + LOGL - STEPS::sum(SI)) <= LOGT - WB;
+  }
+  template <int SI> F64_HD static u32 set_number(u32 tid, int g) {
+    constexpr int k = STEPS::k[SI];
+    if constexpr (NT > 64 && chunk_preserving<SI>())
+      return ((tid >> 6) << (LOGT - k - WB)) | ((u32)g << 6) | (tid & 63u);
+    else
+      return tid + (u32)g * NT;
+  }
+  // Host-side proof of the claim above for this tile shape (tests/test_host_logic.py runs it over the
+  // whole registry): in every step the sets are a bijection onto the tile, and in a
+  // chunk-preserving step every element of wave w lies in chunk w.
+#if !defined(__HIP_DEVICE_COMPILE__)
+  template <int SI = 0> static bool verify_set_mapping() {
+    if constexpr (SI == NSTEPS) {
+      return true;
+    } else {
+      constexpr int k = STEPS::k[SI];
+      constexpr int HI = LOGL - STEPS::sum(SI), LO = HI - k, lo = F0 + LO, hi = F0 + HI;
+      std::vector<unsigned char> seen((size_t)1 << LOGT, 0);
+      for (u32 tid = 0; tid < (u32)NT; ++tid)
+        for (int g = 0; g < (E >> k); ++g)
+          for (u32 v = 0; v < (1u << k); ++v) {
+            const u32 st = set_number<SI>(tid, g);
+            const u32 I = ((st >> lo) << hi) | (v << lo) | (st & ((1u << lo) - 1u));
+            if (I >> LOGT || seen[I]++) return false;
+            if (chunk_preserving<SI>() && NT > 64 && (I >> (LOGT - WB)) != (tid >> 6)) return false;
+          }
+      return verify_set_mapping<SI + 1>();
+    }
+  }
+#endif
+  enum : int { SYNC_NONE = 0, SYNC_WAVE = 1, SYNC_GROUP = 2 };
+  // what must separate step SI from the step executed before it
+  template <int SI> static constexpr int sync_before() {
+    constexpr int prev = (MODE == MODE_FWD) ? SI - 1 : SI + 1;
+    if constexpr (prev < 0 || prev >= NSTEPS)
+      return SYNC_NONE;
+    else
+      return (chunk_preserving<SI>() && chunk_preserving<prev>()) ? SYNC_WAVE : SYNC_GROUP;
+  }
+  template <int KIND> F64_HD static void exchange_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KIND == SYNC_GROUP) {
+      __syncthreads();
+    } else if constexpr (KIND == SYNC_WAVE) {
+      // same wave wrote what it now reads: LDS executes a wave's operations in order; only the
+      // compiler must not move them across this point
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#endif
+  }
+
   struct Tile {
     u64 base;    // element offset of the tile in HBM (destination side)
     u64 sbase;   // same, source side
@@ -342,9 +408,9 @@ struct TileNTT {
   // The same step with all G sets of the thread held at once (x[g*R + v]) and the stages run
   // by the assembly groups of stage_asm.inc, four butterflies per statement.  Loads are issued
   // in source order between the (volatile) assembly statements, so everything that comes from
-  // a table is requested one statement group ahead of its use.  SYNC: the step reads what the
-  // previous step wrote to LDS; the barrier comes after the first twiddle requests.
-  template <int SI, bool SYNC>
+  // a table is requested one statement group ahead of its use.  SYNC (sync_before): what separates
+  // the step from the one that wrote the LDS image it reads; it comes after the first twiddle requests.
+  template <int SI, int SYNC>
   __device__ __forceinline__ static void step_asm(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
     constexpr int k = STEPS::k[SI];
     constexpr int HI = LOGL - STEPS::sum(SI);
@@ -366,14 +432,14 @@ struct TileNTT {
     u32 I0[G], s_low[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const u32 s = tid + (u32)g * NT;
+      const u32 s = set_number<SI>(tid, g);
       s_low[g] = s & ((1u << lo) - 1u);
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
     // first stage's twiddles: requested ahead of the barrier and of the data
     const GroupTwiddles w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low);
     const GroupTwiddles w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low);
-    if constexpr (SYNC) __syncthreads();
+    exchange_sync<SYNC>();
     // ---- gather ------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -536,8 +602,8 @@ struct TileNTT {
 #endif  // SVENTT_STAGE_ASM
 
   // One step for one thread.  `first`/`last` say whether this step touches HBM.
-  // SYNC (device only): a workgroup barrier separates this step from the previous one.
-  template <int SI, bool SYNC = false>
+  // SYNC (device only): sync_before<SI>() when the step follows another one of the same tile.
+  template <int SI, int SYNC = SYNC_NONE>
   F64_HD static void step(const PassArgs &a, const Tile &t, u32 tid, u64 *lds) {
 #if defined(SVENTT_STAGE_ASM)
     if constexpr (LOGE == 4) {
@@ -545,9 +611,7 @@ struct TileNTT {
       return;
     }
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (SYNC) __syncthreads();
-#endif
+    exchange_sync<SYNC>();
     constexpr int k = STEPS::k[SI];
     constexpr int HI = LOGL - STEPS::sum(SI);  // field-relative top bit (exclusive)
     constexpr int LO = HI - k;
@@ -561,7 +625,7 @@ struct TileNTT {
     u64 x[E];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const u32 s = tid + (u32)g * NT;
+      const u32 s = set_number<SI>(tid, g);
       const u32 s_low = s & ((1u << lo) - 1u);
       const u32 I0 = ((s >> lo) << hi) | s_low;
       // lds_phys is XOR-linear and I0 has zeros where v goes, so

@@ -75,7 +75,41 @@ int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src, const u
 
 }  // namespace
 
+// Every tile shape of the three registries: set mapping bijective, chunk-preserving steps wave-local.
+// Returns the number of shapes checked, or -(index + 1) of the first bad one.
+template <class F> int check_table(F find) {
+  int n = 0;
+  for (int kind = 0; kind < 2; ++kind)
+    for (int logl = 1; logl <= 13; ++logl)
+      for (int dir = 0; dir < 2; ++dir)
+        for (int flag = 0; flag < 2; ++flag)
+          for (int f0 = 0; f0 <= 11; ++f0)
+            for (int loge : {2, 4}) {
+              const SimEntry *e = find(kind, logl, dir, flag, f0, loge);
+              if (!e) continue;
+              ++n;
+              if (!e->set_mapping_ok()) return -n;
+            }
+  return n;
+}
+
 extern "C" {
+
+int sim_check_set_mappings(void) {
+  const int a = check_table([](int k, int l, int d, int fl, int f0, int e) {
+    return find_kernel_in_registry<SimEntry, SimLauncher>(k, l, d, fl, f0, e); });
+  if (a < 0) return a;
+  const int b = check_table([](int k, int l, int d, int fl, int f0, int e) {
+    return find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(k, l, d, fl, f0, e); });
+  if (b < 0) return b - 100000;
+  return a + b;
+}
+
+// workgroup barriers per tile of the kernel that serves a pass shape (-1: no such kernel)
+int sim_group_barriers(int kind, int logl, int dir, int flag, int f0, int loge) {
+  const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(kind, logl, dir, flag, f0, loge);
+  return e ? e->group_barriers : -1;
+}
 
 const char *sim_last_error(void) { return g_err.c_str(); }
 

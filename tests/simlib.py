@@ -39,6 +39,10 @@ def load() -> ctypes.CDLL:
         L.sim_last_error.restype = ctypes.c_char_p
         L.sim_transform.restype = _int
         L.sim_transform.argtypes = [_u64, _u64, _u64, _u32, _u64, _int, _p64, _p64]
+        L.sim_check_set_mappings.restype = _int
+        L.sim_check_set_mappings.argtypes = []
+        L.sim_group_barriers.restype = _int
+        L.sim_group_barriers.argtypes = [_int] * 6
         L.sim_transform_flags.restype = _int
         L.sim_transform_flags.argtypes = [_u64, _u64, _u64, _u32, _u64, _int, _u32, _p64, _p64]
         L.sim_forward_multiply.restype = _int

@@ -191,6 +191,19 @@ def test_lds_swizzle_is_a_bijection_and_conflict_free():
     assert worst <= 2, worst
 
 
+def test_set_mappings_are_bijective_and_wave_local():
+    """tile_ntt.h "which thread holds which radix set": in every step of every registered tile shape the
+    sets cover the tile exactly once, and in chunk-preserving steps each wave holds only its own chunk
+    (which is what lets the exchange between two such steps skip the workgroup barrier)."""
+    from tests import simlib
+    L = simlib.load()
+    assert L.sim_check_set_mappings() > 200  # tile shapes checked (negative: the first bad one)
+    # the two N = 2^24 kernels: one workgroup barrier per tile (r01: three and two)
+    assert L.sim_group_barriers(0, 13, 0, 0, 0, 4) == 1   # ROW 2^13 forward, Steps<4,4,4,1>
+    assert L.sim_group_barriers(1, 11, 0, 1, 2, 4) == 1   # COL 2^11 x T4 forward, Steps<4,4,3>
+    assert L.sim_group_barriers(0, 13, 1, 0, 0, 4) == 1 and L.sim_group_barriers(1, 11, 1, 1, 2, 4) == 1
+
+
 def test_c_abi_exports_every_declared_symbol():
     from sve_ntt_amd import _lib
     lib = _lib.load()  # raises if the .so is missing: there is no fallback
