@@ -40,6 +40,16 @@ template <class TN> struct SimLauncher {
 
 using SimEntry = KernelEntryT<int, int>;
 
+// the tile code of the pass's arithmetic back end (field64.h)
+const SimEntry *find_sim_kernel(const HostPass &h, int flag) {
+  const int dir = h.inverse ? MODE_INV : MODE_FWD;
+  if (h.arith == ARITH_GOLD)
+    return find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
+  if (h.arith == ARITH_SHOUP)
+    return find_arith_kernel_in_registry<ARITH_SHOUP, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
+  return find_kernel_in_registry<SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
+}
+
 thread_local std::string g_err;
 
 // `epilogue` (forward only): the fused product of sventt_forward_multiply -- the final
@@ -54,13 +64,7 @@ int run_plan(const HostPlan &pl, bool inverse, u64 *dst, const u64 *src, const u
   for (size_t i = 0; i < passes.size(); ++i) {
     const HostPass &h = passes[i];
     const bool fused = epilogue && i + 1 == passes.size();
-    const int dir = h.inverse ? MODE_INV : MODE_FWD, flag = (h.flag || fused) ? 1 : 0;
-    const SimEntry *e =
-        h.arith == ARITH_GOLD
-            ? find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge)
-        : h.arith == ARITH_SHOUP
-            ? find_arith_kernel_in_registry<ARITH_SHOUP, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge)
-            : find_kernel_in_registry<SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
+    const SimEntry *e = find_sim_kernel(h, (h.flag || fused) ? 1 : 0);
     if (!e || e->f0 != h.f0 || e->logt != h.logt || (fused && h.kind != KIND_ROW)) {
       g_err = "registry mismatch";
       return PLAN_ERR_LOGIC;
@@ -169,8 +173,7 @@ int sim_sharded_rows_pass(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, i
   const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
   if (index < 0 || (size_t)index >= passes.size()) return PLAN_ERR_INVALID_ARGUMENT;
   const HostPass &h = passes[(size_t)index];
-  const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
+  const SimEntry *e = find_sim_kernel(h, h.flag ? 1 : 0);
   if (!e) return PLAN_ERR_LOGIC;
   if (dst == src && (h.src_istride != h.dst_istride || h.src_ostride != h.dst_ostride)) {
     g_err = "gather/scatter passes cannot run in place";
@@ -194,8 +197,7 @@ int sim_sharded_chunk(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, int r
   if (rc) return rc;
   const std::vector<HostPass> &passes = inverse ? pl.inv : pl.fwd;
   const HostPass &h = (which == 1 && inverse) ? passes.back() : passes.front();
-  const SimEntry *e = find_kernel_in_registry<SimEntry, SimLauncher>(
-      h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge);
+  const SimEntry *e = find_sim_kernel(h, h.flag ? 1 : 0);
   if (!e) return PLAN_ERR_LOGIC;
   PassArgs a;
   u32 grid = 0;

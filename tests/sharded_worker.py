@@ -47,6 +47,9 @@ def main() -> None:
         device = torch.device("cpu")
     rank, world = dist.get_rank(), dist.get_world_size()
     P, G = oracle.BASELINE_P, oracle.BASELINE_G
+    if os.environ.get("MODULUS") == "goldilocks":  # its own kernel family (field64.h: ARITH_GOLD)
+        P, G = oracle.GOLDILOCKS_P, 7
+    modulus = eng.Modulus(P, G)
     port = oracle.port()
     n = 1 << log2n
     R = 1 << r_log2
@@ -68,9 +71,9 @@ def main() -> None:
     engine = None
     if engine_kind == "sim":
         from tests.simlib import SimShardEngine
-        engine = SimShardEngine(eng.BASELINE_MODULUS, n, r_log2, rank, world)
+        engine = SimShardEngine(modulus, n, r_log2, rank, world)
     chunks = int(os.environ.get("CHUNKS", "4"))
-    sh = ShardedNTT(eng.BASELINE_MODULUS, n, dist, r_log2=r_log2, engine=engine, device=device,
+    sh = ShardedNTT(modulus, n, dist, r_log2=r_log2, engine=engine, device=device,
                     chunks=chunks)
 
     src = torch.from_numpy(slab.view(np.int64).copy()).to(device)

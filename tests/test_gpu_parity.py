@@ -283,6 +283,31 @@ def test_arithmetic_back_ends_extreme_values(eng, port):
             assert np.array_equal(host(d), src)
 
 
+@pytest.mark.parametrize("arith,N,g", [("auto", oracle.GOLDILOCKS_P, 7), ("fixed_point", oracle.TEST62_P, 3)])
+@pytest.mark.parametrize("log2m,batch", [(3, 2), (12, 3), (13, 1), (17, 1), (20, 1)])
+def test_fused_product_on_the_other_back_ends(eng, port, arith, N, g, log2m, batch):
+    """sventt_forward_multiply keeps its contract (operand in Montgomery form) whatever arithmetic the
+    butterflies use, and the inverse divisor is honoured there too."""
+    m = 1 << log2m
+    src = port.fill_splitmix(m * batch, 3 + log2m, N)
+    operand = port.fill_splitmix(m * batch, 5 + log2m, N)
+    ntt = eng.NTT(eng.Modulus(N, g), m, batch=batch, arithmetic=arith, inverse_divisor=1)
+    s, o = dev(src), dev(operand)
+    om = torch.empty_like(o)
+    ntt.to_montgomery(om, o)
+    fused = torch.full_like(s, 0x5555555555555555)
+    ntt.compute_forward_multiply(fused, s, om)
+    for b in range(batch):
+        f = port.forward(src[b * m:(b + 1) * m], N, g)
+        want = np.array((f.astype(object) * operand[b * m:(b + 1) * m].astype(object)) % N, dtype=np.uint64)
+        assert np.array_equal(host(fused)[b * m:(b + 1) * m], want), (arith, b)
+    d = dev(src)
+    ntt.compute_forward(d)
+    ntt.compute_inverse(d)  # divisor 1: the unscaled inverse = m * x
+    want = np.array((src.astype(object) * m) % N, dtype=np.uint64)
+    assert np.array_equal(host(d), want)
+
+
 def test_fixed_point_needs_a_modulus_below_2p63(eng):
     with pytest.raises(ValueError):  # SVENTT_ERR_INVALID_ARGUMENT
         eng.NTT(eng.Modulus(P, G), 1 << 10, arithmetic="fixed_point")

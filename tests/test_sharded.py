@@ -54,6 +54,18 @@ def test_sharded_gloo_closed_form_check(world, log2n, r_log2, chunks):
     assert "forward=OK" in out and "inverse=OK" in out and "closed-form" in out, out
 
 
+def test_sharded_gloo_goldilocks():
+    """the sharded plans pick the Goldilocks back end for p = 2^64 - 2^32 + 1 like the local ones"""
+    out = _run(2, {"ENGINE": "sim", "LOG2N": "16", "R_LOG2": "6", "CHUNKS": "2", "MODULUS": "goldilocks"})
+    assert "forward=OK" in out and "inverse=OK" in out, out
+
+
+@pytest.mark.gpu
+def test_sharded_two_ranks_goldilocks_on_one_gpu():
+    out = _run(2, {"ENGINE": "hip", "LOG2N": "22", "R_LOG2": "10", "MODULUS": "goldilocks"}, timeout=600)
+    assert "forward=OK" in out and "inverse=OK" in out, out
+
+
 @pytest.mark.gpu
 def test_sharded_two_ranks_closed_form_on_one_gpu():
     """The same mode through the HIP kernels at 2^27 (two ranks share the card; host-bounced
