@@ -90,7 +90,8 @@ class ShardedNTT:
     ``src``/``dst`` are this rank's ``n / world`` elements (int64 tensors holding
     uint64 residues): the column slab on the natural-order side, the row block on
     the bit-reversed side.  ``chunks``: pieces the exchange is pipelined in
-    (default: env SVENTT_A2A_CHUNKS or 4, reduced to what the tile counts allow).
+    (default: env SVENTT_A2A_CHUNKS, else 1 for two ranks and 4 otherwise; reduced to what
+    the tile counts allow).
     """
 
     def __init__(self, modulus: Modulus, n: int, dist, r_log2: int = 11, engine=None,
@@ -109,7 +110,12 @@ class ShardedNTT:
         self.engine = engine or HipShardEngine(modulus, n, r_log2, self.rank, self.world)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if engine is None else "cpu"
-        want = chunks if chunks is not None else int(os.environ.get("SVENTT_A2A_CHUNKS", "4"))
+        # Two ranks exchange half of their data over ONE xGMI link: the exchange is several times
+        # longer than the column pass, there is little to hide and cutting the pass into four
+        # launches costs 139 against 120 us (profiles/r01/ubench_copy_and_sharded_local.txt), so the
+        # default is one launch per phase there and four chunks from four ranks on.
+        default_chunks = "1" if self.world == 2 else "4"
+        want = chunks if chunks is not None else int(os.environ.get("SVENTT_A2A_CHUNKS", default_chunks))
         k = max(1, want)
         while k > 1 and any(lim % k for lim in self.engine.chunk_limits):
             k -= 1
