@@ -47,33 +47,40 @@ def zero_ext_init(S):
     return []
 
 
+def hi_chain(S, x0, x1, y0, y1, low, mid, top, first):
+    """top <- hi64(x * y), mid.lo <- bits 32..63 of the product (`first`: the instruction(s) that leave
+    low = x0*y0 [+0], whose high word feeds the chain -- or put bits 32..63 of x0*y0 into z directly).
+    The two cross products are summed in ONE 64-bit accumulator; the carry of that sum (SGPR pair
+    S.sc, the carry-out of v_mad_u64_u32) is worth 2^32 in the top product and goes in with a
+    v_addc on its high word.  Against adding the cross products' halves separately this saves two
+    zero-extending v_mov per product and the 64-bit add (r02: 7 -> 3 v_mov per Montgomery product)."""
+    z = S.z
+    return first + [
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(mid), x0, y1, pair(z)),
+        'v_mad_u64_u32 %s, %s, %s, %s, %s' % (pair(mid), S.sc, x1, y0, pair(mid)),
+        'v_mov_b32 v%d, v%d' % (z, mid + 1),
+        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(top), x1, y1, pair(z)),
+        'v_addc_co_u32 v%d, vcc, 0, v%d, %s' % (top + 1, top + 1, S.sc),
+    ]
+
+
 def mont(S, al, ah, w0, w1):
     """h <- hi64(a*w), m2 <- hi64(q*N) with q = lo64(a*w) * N^-1 mod 2^64 (field64.h: montmul).
     al/ah: the multiplicand's halves (VGPR operand texts); w0/w1: the multiplier's (VGPR or SGPR)."""
     m0, m1, m2, h, z = S.m0, S.m1, S.m2, S.h, S.z
-    return [
-        'v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(m0), al, w0),
-        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
-        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m1), al, w1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m1 + 1),
-        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(h), ah, w1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m1),
-        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, w0, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m2 + 1),
-        'v_mad_u64_u32 %s, vcc, v%d, %%[ni0], 0' % (pair(m1), m0),
-        'v_mul_lo_u32 v%d, v%d, %%[ni1]' % (m0 + 1, m0),
-        'v_mul_lo_u32 v%d, v%d, %%[ni0]' % (m2, m2),
-        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),
-        'v_add3_u32 v%d, v%d, v%d, v%d' % (m1 + 1, m1 + 1, m0 + 1, m2),
-        'v_mul_hi_u32 v%d, v%d, %%[n0]' % (z, m1),
-        'v_mad_u64_u32 %s, vcc, v%d, %%[n1], %s' % (pair(m0), m1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
-        'v_mad_u64_u32 %s, vcc, v%d, %%[n1], %s' % (pair(m2), m1 + 1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m0),
-        'v_mad_u64_u32 %s, vcc, v%d, %%[n0], %s' % (pair(m0), m1 + 1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
-        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(m2), pair(m2), pair(z)),
-    ]
+    return (
+        # a * w: t0 = m0.lo, t1 = m2.lo, h = (t2, t3)
+        hi_chain(S, al, ah, w0, w1, m0, m2, h,
+                 ['v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(m0), al, w0),
+                  'v_mov_b32 v%d, v%d' % (z, m0 + 1)]) +
+        # q = (t0, t1) * N^-1 mod 2^64 -> (m1.lo, m1.hi)
+        ['v_mad_u64_u32 %s, vcc, v%d, %%[ni0], 0' % (pair(m1), m0),
+         'v_mul_lo_u32 v%d, v%d, %%[ni1]' % (m0 + 1, m0),
+         'v_mul_lo_u32 v%d, v%d, %%[ni0]' % (m2, m2),
+         'v_add3_u32 v%d, v%d, v%d, v%d' % (m1 + 1, m1 + 1, m0 + 1, m2)] +
+        # m2 <- hi64(q * N); the low half of q * N is a * w's and is never formed
+        hi_chain(S, 'v%d' % m1, 'v%d' % (m1 + 1), '%[n0]', '%[n1]', None, m0, m2,
+                 ['v_mul_hi_u32 v%d, v%d, %%[n0]' % (z, m1)]))
 
 
 def fix_if(S_mask, reg, addend='%[N]'):
@@ -102,18 +109,10 @@ ARITHS = ('ARITH_MONT', 'ARITH_GOLD', 'ARITH_SHOUP')
 
 def product128(S, al, ah, w0, w1):
     """m0.lo = t0, m2.lo = t1, h = (t2, t3) of a * w"""
-    m0, m1, m2, h, z = S.m0, S.m1, S.m2, S.h, S.z
-    return [
-        'v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(m0), al, w0),
-        'v_mov_b32 v%d, v%d' % (z, m0 + 1),
-        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m1), al, w1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m1 + 1),
-        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(h), ah, w1, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m1),
-        'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, w0, pair(z)),
-        'v_mov_b32 v%d, v%d' % (z, m2 + 1),
-        'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),
-    ]
+    m0, m2, h, z = S.m0, S.m2, S.h, S.z
+    return hi_chain(S, al, ah, w0, w1, m0, m2, h,
+                    ['v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(m0), al, w0),
+                     'v_mov_b32 v%d, v%d' % (z, m0 + 1)])
 
 
 def gold_mul(S, al, ah, w0, w1, dst):
@@ -134,14 +133,8 @@ def shoup_mul(S, al, ah, w0, w1, p0, p1, dst):
     """v[dst:dst+1] = a*w - hi64(a*w')*N, then -N if >= N (field64.h: shoup_mul); dst must not
     hold a.  negN = 2^64 - N as (nn0, nn1)."""
     m1, m2, h, z = S.m1, S.m2, S.h, S.z
-    return ['v_mul_hi_u32 v%d, %s, %s' % (z, al, p0),
-            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m1), al, p1, pair(z)),
-            'v_mov_b32 v%d, v%d' % (z, m1 + 1),
-            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(h), ah, p1, pair(z)),
-            'v_mov_b32 v%d, v%d' % (z, m1),
-            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(m2), ah, p0, pair(z)),
-            'v_mov_b32 v%d, v%d' % (z, m2 + 1),
-            'v_lshl_add_u64 %s, %s, 0, %s' % (pair(h), pair(h), pair(z)),           # q = hi64(a * w')
+    return hi_chain(S, al, ah, p0, p1, None, m1, h,                                 # q = hi64(a * w')
+                    ['v_mul_hi_u32 v%d, %s, %s' % (z, al, p0)]) + [
             'v_mad_u64_u32 %s, vcc, %s, %s, 0' % (pair(dst), al, w0),
             'v_mad_u64_u32 %s, vcc, v%d, %%[nn0], %s' % (pair(dst), h, pair(dst)),  # + q0 * negN0
             'v_mov_b32 v%d, v%d' % (m2, dst + 1),                                   # high word: only m2.lo counts
