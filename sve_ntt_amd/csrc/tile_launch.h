@@ -37,7 +37,7 @@ __global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1) vo
 
 template <class TN>
 inline hipError_t launch_tile(const PassArgs &a, u32 grid, hipStream_t stream) {
-  constexpr size_t lds_bytes = (TN::NSTEPS > 1) ? (sizeof(u64) << TN::LOGT) : 0;
+  constexpr size_t lds_bytes = TN::LDS_BYTES;  // tile image + the lower steps' twiddles
   if constexpr (lds_bytes > 48 * 1024) {
     // the opt-in to more than 48 KiB of dynamic LDS is a per-device property of the function:
     // one bit per device ordinal, set once the attribute call succeeded there

@@ -134,6 +134,30 @@ struct TileNTT {
   static_assert(LOGT >= LOGE && F0 + LOGL <= LOGT, "tile too small");
   static_assert(!COL || F0 + LOGL == LOGT, "a COL tile holds whole columns");
 
+  // ---- stage twiddles of the lower steps live in LDS ----------------------------------------
+  // The vector L1 returns data in order: a twiddle load that hits in L2 still waits behind the
+  // HBM loads and stores the CU's other workgroup has in flight (a build without twiddle loads
+  // runs 8 % faster, one without HBM traffic barely notices them: profiles/r02/asm_stages_ab.txt).
+  // The tables of every step below the top one are a PREFIX of the stage table (stage bit p at
+  // [2^p - 1, 2^(p+1) - 1), the top step owns the largest LOGL - k[0] .. LOGL - 1): at most
+  // 511 entries.  The first step a tile executes copies that prefix behind the tile image (one
+  // load per thread, issued ahead of the data) and the middle steps read their twiddles with
+  // ds_read; the lowest step's indices are compile-time constants and stay scalar loads.
+  // Measured (profiles/r02/asm_stages_ab.txt): 2^16 x 2^12 forward -10 %, inverse -6 %; N = 2^24 inverse
+  // -2.6 %, forward row pass -2.5 %; the forward column pass gains nothing (one step of three reads the
+  // copy, and the card runs into its power limit, section 4 of DESIGN.md), so it keeps its table loads.
+#if !defined(SVENTT_TW_LDS)  // analysis builds: 0 = none, 1 = all but forward COL tiles, 2 = all
+#define SVENTT_TW_LDS 1
+#endif
+  static constexpr int TW_LDS_P =
+      (LOGE == 4 && NSTEPS >= 3 && (SVENTT_TW_LDS == 2 || (SVENTT_TW_LDS == 1 && !(COL && MODE == MODE_FWD))))
+          ? LOGL - STEPS::k[0]
+          : 0;
+  static constexpr u32 TW_LDS_WORDS = TW_LDS_P > 0 ? ((1u << TW_LDS_P) - 1u) * (u32)TWW : 0u;
+  static constexpr u32 TW_LDS_PER_THREAD = (TW_LDS_WORDS + (u32)NT - 1u) / (u32)NT;
+  static constexpr size_t LDS_BYTES =
+      NSTEPS > 1 ? (sizeof(u64) << LOGT) + (((size_t)TW_LDS_WORDS * sizeof(u64) + 15u) & ~(size_t)15u) : 0;
+
   // ---- which thread holds which radix set ----------------------------------------------
   // Set number s (LOGT - k bits) names the 2^k elements I = ((s >> lo) << hi) | (v << lo) |
   // (s mod 2^lo).  Wave w of the workgroup owns the contiguous CHUNK [w, w + 1) * 2^(LOGT - WB)
@@ -436,10 +460,29 @@ struct TileNTT {
       s_low[g] = s & ((1u << lo) - 1u);
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
-    // first stage's twiddles: requested ahead of the barrier and of the data
-    const GroupTwiddles w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low);
-    const GroupTwiddles w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low);
+    // the table prefix the middle steps read from LDS: asked for first, so that it arrives first
+    constexpr bool tw_fill = TW_LDS_WORDS > 0 && from_hbm;
+    u64 twl[TW_LDS_PER_THREAD > 0 ? TW_LDS_PER_THREAD : 1];
+    if constexpr (tw_fill) {
+#pragma unroll
+      for (u32 i = 0; i < TW_LDS_PER_THREAD; ++i) {
+        const u32 idx = tid + i * (u32)NT;
+        twl[i] = idx < TW_LDS_WORDS ? a.stage_tw[idx] : 0;
+      }
+    }
+    // first stage's twiddles: from a table in HBM/L2 they are requested ahead of the barrier and
+    // of the data; from the LDS copy after the barrier (which may be what publishes the copy)
+    constexpr bool tw_in_lds = TW_LDS_WORDS > 0 && LO > 0 && LO + k <= TW_LDS_P;
+    GroupTwiddles w0, w1;
+    if constexpr (!tw_in_lds) {
+      w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low, lds);
+      w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
+    }
     exchange_sync<SYNC>();
+    if constexpr (tw_in_lds) {
+      w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low, lds);
+      w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
+    }
     // ---- gather ------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -459,6 +502,18 @@ struct TileNTT {
         for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
       }
     }
+    if constexpr (tw_fill) {
+      // (the data loads above are in flight; every wave is waiting for them anyway)
+#pragma unroll
+      for (u32 i = 0; i < TW_LDS_PER_THREAD; ++i) {
+        const u32 idx = tid + i * (u32)NT;
+        if (idx < TW_LDS_WORDS) lds[((size_t)1 << LOGT) + idx] = twl[i];
+      }
+      // forward: the workgroup barrier behind this (top) step comes before the first reader
+      // (step_asm asks for LDS twiddles after its exchange_sync) -- unless every step of the tile
+      // exchanges inside its wave.  inverse: the next steps are wave-local, no barrier comes in time.
+      if constexpr (MODE == MODE_INV || sync_before<1>() != SYNC_GROUP) __syncthreads();
+    }
     if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), zr, c);
     // ---- k fused stages ------------------------------------------------------
     TwistFactors f0;
@@ -471,7 +526,7 @@ struct TileNTT {
     // stage is a full butterfly stage; the forward passes end on a twist or a short stage and lose
     // more to the unmerged stores than they gain, so they keep storing at the end.
     constexpr bool early = SVENTT_EARLY_STORES != 0 && to_hbm && COL && MODE == MODE_INV;
-    stages_asm<k, LO, lo, 0, twist_out, multiply_out, early>(a, t, x, I0, s_low, w0, w1, f0, o0, zr, c);
+    stages_asm<k, LO, lo, 0, twist_out, multiply_out, early>(a, t, lds, x, I0, s_low, w0, w1, f0, o0, zr, c);
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
       if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, zr, c);
@@ -522,11 +577,14 @@ struct TileNTT {
     u64 p[4];  // ARITH_SHOUP: the precomputed companions w' = floor(w * 2^64 / N)
   };
   template <int k, int LO, int lo, int rr, int GRP>
-  __device__ __forceinline__ static GroupTwiddles group_twiddles(const PassArgs &a, const u32 (&s_low)[E >> k]) {
+  __device__ __forceinline__ static GroupTwiddles group_twiddles(const PassArgs &a, const u32 (&s_low)[E >> k],
+                                                                 const u64 *lds) {
     constexpr int r = (MODE == MODE_FWD) ? (k - 1 - rr) : rr;
     constexpr int ps = LO + r;
     constexpr bool triv = stage_has_unit_twiddles<LO, ps>();
-    const u64 *tab = a.stage_tw + (size_t)((1u << ps) - 1u) * TWW;
+    // a middle step (below the top one, indices not compile-time constants) reads the LDS copy
+    constexpr bool in_lds = TW_LDS_WORDS > 0 && LO > 0 && LO + k <= TW_LDS_P;
+    const u64 *tab = (in_lds ? lds + ((size_t)1 << LOGT) : a.stage_tw) + (size_t)((1u << ps) - 1u) * TWW;
     GroupTwiddles tw;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -571,7 +629,7 @@ struct TileNTT {
   // Ahead of the step's last group the first quarter of what the scatter multiplies by is
   // requested too (TW: twist factors into f0, MUL: operands of the fused product into o0).
   template <int k, int LO, int lo, int rr, bool TW, bool MUL, bool SCATTER = false>
-  __device__ __forceinline__ static void stages_asm(const PassArgs &a, const Tile &t, u64 (&x)[E],
+  __device__ __forceinline__ static void stages_asm(const PassArgs &a, const Tile &t, const u64 *lds, u64 (&x)[E],
                                                     const u32 (&I0)[E >> k], const u32 (&s_low)[E >> k],
                                                     const GroupTwiddles &w0, const GroupTwiddles &w1,
                                                     TwistFactors &f0, Operands &o0, u32 (&zr)[4],
@@ -586,10 +644,10 @@ struct TileNTT {
       ScaleGroup<r, 1>::run(x, a.scale, zr, c);
     }
     GroupTwiddles n0, n1;
-    if constexpr (more) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low);
+    if constexpr (more) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low, lds);
     BflyGroup<ARITH, MODE, r, 0, triv>::run(x, w0.w[0], w0.w[1], w0.w[2], w0.w[3], w0.p[0], w0.p[1], w0.p[2],
                                             w0.p[3], zr, c);
-    if constexpr (more) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low);
+    if constexpr (more) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low, lds);
     if constexpr (!more && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
     if constexpr (!more && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
     if constexpr (!more && SCATTER) store_group<k, LO, r, 0>(a, t, x, I0);  // final: out they go
@@ -597,7 +655,7 @@ struct TileNTT {
                                             w1.p[3], zr, c);
     if constexpr (!more && SCATTER) store_group<k, LO, r, 1>(a, t, x, I0);
     if constexpr (more)
-      stages_asm<k, LO, lo, rr + 1, TW, MUL, SCATTER>(a, t, x, I0, s_low, n0, n1, f0, o0, zr, c);
+      stages_asm<k, LO, lo, rr + 1, TW, MUL, SCATTER>(a, t, lds, x, I0, s_low, n0, n1, f0, o0, zr, c);
   }
 #endif  // SVENTT_STAGE_ASM
 
