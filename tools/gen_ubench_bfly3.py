@@ -57,8 +57,35 @@ def mont_core(S, dl, dh):
     ]
 
 
+def mont_core_chain(S, dl, dh):
+    """the shipped form (csrc/gen_stage_asm.py: hi_chain): the two cross products share one 64-bit
+    accumulator, its carry (the SGPR carry-out of v_mad_u64_u32) enters the top word with v_addc"""
+    m0, m1, m2, h, z = S.m0, S.m1, S.m2, S.h, S.z
+
+    def chain(x0, x1, y0, y1, mid, top, first):
+        return first + [
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(mid), x0, y1, pair(z)),
+            'v_mad_u64_u32 %s, %s, %s, %s, %s' % (pair(mid), S.sc, x1, y0, pair(mid)),
+            'v_mov_b32 v%d, v%d' % (z, mid + 1),
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(top), x1, y1, pair(z)),
+            'NOPGAP',
+            'v_addc_co_u32 v%d, vcc, 0, v%d, %s' % (top + 1, top + 1, S.sc),
+        ]
+    return (chain('v%d' % dl, 'v%d' % dh, S.w0, S.w1, m2, h,
+                  ['v_mad_u64_u32 %s, vcc, v%d, %s, 0' % (pair(m0), dl, S.w0),
+                   'v_mov_b32 v%d, v%d' % (z, m0 + 1)]) +
+            ['v_mad_u64_u32 %s, vcc, v%d, %%[ni0], 0' % (pair(m1), m0),
+             'v_mul_lo_u32 v%d, v%d, %%[ni1]' % (m0 + 1, m0),
+             'v_mul_lo_u32 v%d, v%d, %%[ni0]' % (m2, m2),
+             'v_add3_u32 v%d, v%d, v%d, v%d' % (m1 + 1, m1 + 1, m0 + 1, m2)] +
+            chain('v%d' % m1, 'v%d' % (m1 + 1), '%[n0]', '%[n1]', m0, m2,
+                  ['v_mul_hi_u32 v%d, v%d, %%[n0]' % (z, m1)]))
+
+
 import os
 FIXMODE = os.environ.get('FIXMODE', 'exec')
+if os.environ.get('MONT', 'chain') == 'chain':  # MONT=movs: the r02a form with seven zero-extending v_mov
+    mont_core = mont_core_chain
 def fix(mask_expr, reg):
     if FIXMODE == 'none':
         return []
