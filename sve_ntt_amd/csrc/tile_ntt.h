@@ -150,7 +150,8 @@ struct TileNTT {
 #define SVENTT_TW_LDS 1
 #endif
   static constexpr int TW_LDS_P =
-      (LOGE == 4 && NSTEPS >= 3 && (SVENTT_TW_LDS == 2 || (SVENTT_TW_LDS == 1 && !(COL && MODE == MODE_FWD))))
+      (LOGE == 4 && NSTEPS >= 3 &&
+       (SVENTT_TW_LDS == 2 || (SVENTT_TW_LDS == 1 && !(COL && MODE == MODE_FWD && TWW == 1))))  // (two-word twiddles: always, for the registers)
           ? LOGL - STEPS::k[0]
           : 0;
   static constexpr u32 TW_LDS_WORDS = TW_LDS_P > 0 ? ((1u << TW_LDS_P) - 1u) * (u32)TWW : 0u;
@@ -479,7 +480,7 @@ struct TileNTT {
       w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
     }
     exchange_sync<SYNC>();
-    if constexpr (tw_in_lds) {
+    if constexpr (tw_in_lds && TWW == 1) {  // (two-word twiddles are read group by group: stages_asm)
       w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low, lds);
       w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
     }
@@ -643,17 +644,29 @@ struct TileNTT {
       ScaleGroup<r, 0>::run(x, a.scale, zr, c);
       ScaleGroup<r, 1>::run(x, a.scale, zr, c);
     }
-    GroupTwiddles n0, n1;
-    if constexpr (more) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low, lds);
-    BflyGroup<ARITH, MODE, r, 0, triv>::run(x, w0.w[0], w0.w[1], w0.w[2], w0.w[3], w0.p[0], w0.p[1], w0.p[2],
-                                            w0.p[3], zr, c);
-    if constexpr (more) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low, lds);
+    // Two-word twiddles (ARITH_SHOUP) take 16 registers per group: three groups in flight do not
+    // fit beside the data and the temporaries (30-64 spilled VGPRs).  From the LDS copy they are
+    // read right before their group (one group live), from the table in L2 one GROUP ahead
+    // instead of one stage (two groups live).
+    constexpr bool short_lookahead = TWW == 2;
+    constexpr bool jit = TWW == 2 && TW_LDS_WORDS > 0 && LO > 0 && LO + k <= TW_LDS_P;
+    GroupTwiddles n0, n1, j0, j1;
+    if constexpr (jit) j0 = group_twiddles<k, LO, lo, rr, 0>(a, s_low, lds);
+    const GroupTwiddles &u0 = jit ? j0 : w0;
+    if constexpr (more && !short_lookahead) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low, lds);
+    BflyGroup<ARITH, MODE, r, 0, triv>::run(x, u0.w[0], u0.w[1], u0.w[2], u0.w[3], u0.p[0], u0.p[1], u0.p[2],
+                                            u0.p[3], zr, c);
+    if constexpr (jit) j1 = group_twiddles<k, LO, lo, rr, 1>(a, s_low, lds);
+    const GroupTwiddles &u1 = jit ? j1 : w1;
+    if constexpr (more && short_lookahead && !jit) n0 = group_twiddles<k, LO, lo, rr + 1, 0>(a, s_low, lds);
+    if constexpr (more && !short_lookahead) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low, lds);
     if constexpr (!more && TW) f0 = twist_load<k, LO, 0>(a, t, I0);
     if constexpr (!more && MUL) o0 = epilogue_load<k, LO, 0>(a, t, I0);
     if constexpr (!more && SCATTER) store_group<k, LO, r, 0>(a, t, x, I0);  // final: out they go
-    BflyGroup<ARITH, MODE, r, 1, triv>::run(x, w1.w[0], w1.w[1], w1.w[2], w1.w[3], w1.p[0], w1.p[1], w1.p[2],
-                                            w1.p[3], zr, c);
+    BflyGroup<ARITH, MODE, r, 1, triv>::run(x, u1.w[0], u1.w[1], u1.w[2], u1.w[3], u1.p[0], u1.p[1], u1.p[2],
+                                            u1.p[3], zr, c);
     if constexpr (!more && SCATTER) store_group<k, LO, r, 1>(a, t, x, I0);
+    if constexpr (more && short_lookahead && !jit) n1 = group_twiddles<k, LO, lo, rr + 1, 1>(a, s_low, lds);
     if constexpr (more)
       stages_asm<k, LO, lo, rr + 1, TW, MUL, SCATTER>(a, t, lds, x, I0, s_low, n0, n1, f0, o0, zr, c);
   }
