@@ -8,6 +8,17 @@
 #include "kernels.h"
 #include "tile_launch.h"
 
+#if defined(SVENTT_TRACE)
+// analysis builds only (tools/trace_tiles.py): the time stamps of the last tile-kernel launch
+extern "C" int sventt_debug_trace_read(unsigned long long *host, size_t words) {
+  const size_t all = (size_t)sventt_hip::TRACE_MAX_WAVES * sventt_hip::TRACE_SLOTS;
+  if (words > all) words = all;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(sventt_hip::g_trace), words * sizeof(unsigned long long), 0,
+                             hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace sventt_hip {
 
 // dst[i] = a[i]*b[i] mod p (both plain residues < p): montmul(a, b) = a*b/R, then *R^2/R.

@@ -32,7 +32,30 @@ __global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1) vo
   u64 *lds = reinterpret_cast<u64 *>(smem);
   const typename TN::Tile t = TN::locate(a, blockIdx.x);
   if (!t.live) return;  // whole workgroup: no barrier is skipped by part of it
+#if defined(SVENTT_TRACE)
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same on every XCD
+#endif
   run_steps<TN, 0>(a, t, threadIdx.x, lds);
+#if defined(SVENTT_TRACE)
+  if constexpr (TN::LOGE == 4 && TN::NSTEPS > 1) {
+    // slot 30: end of the instruction stream (stores issued, not acknowledged); slot 31: where it ran
+    const unsigned long long tm = __builtin_amdgcn_s_memtime();
+    const u32 hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    u64 *tr = lds + TN::TRACE_LDS_WORD + wave * TRACE_SLOTS;
+    if (lane == 0) {
+      tr[28] = rt0;
+      tr[29] = __builtin_amdgcn_s_memrealtime();
+      tr[30] = tm;
+      tr[31] = ((u64)blockIdx.x << 32) | hw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t w = (size_t)blockIdx.x * (TN::NT / 64) + wave;
+    if (lane < (u32)TRACE_SLOTS && w < (size_t)TRACE_MAX_WAVES) g_trace[w * TRACE_SLOTS + lane] = tr[lane];
+  }
+#endif
 }
 
 template <class TN>

@@ -51,6 +51,15 @@ enum : int { MODE_FWD = 0, MODE_INV = 1 };
 #endif
 
 // Arguments of one pass (passed by value to the kernel: lives in SGPRs).
+#if defined(SVENTT_TRACE)  // analysis builds only (tools/trace_tiles.py): per-wave time stamps of a tile's phases
+constexpr int TRACE_SLOTS = 32;
+constexpr int TRACE_MAX_WAVES = 1 << 15;
+__device__ unsigned long long g_trace[(size_t)TRACE_MAX_WAVES * TRACE_SLOTS];
+#define SVENTT_TRACE_LDS_BYTES (16 * TRACE_SLOTS * 8)
+#else
+#define SVENTT_TRACE_LDS_BYTES 0
+#endif
+
 struct PassArgs {
   u64 *dst;
   const u64 *src;
@@ -157,7 +166,19 @@ struct TileNTT {
   static constexpr u32 TW_LDS_WORDS = TW_LDS_P > 0 ? ((1u << TW_LDS_P) - 1u) * (u32)TWW : 0u;
   static constexpr u32 TW_LDS_PER_THREAD = (TW_LDS_WORDS + (u32)NT - 1u) / (u32)NT;
   static constexpr size_t LDS_BYTES =
-      NSTEPS > 1 ? (sizeof(u64) << LOGT) + (((size_t)TW_LDS_WORDS * sizeof(u64) + 15u) & ~(size_t)15u) : 0;
+      NSTEPS > 1 ? (sizeof(u64) << LOGT) + (((size_t)TW_LDS_WORDS * sizeof(u64) + 15u) & ~(size_t)15u) +
+                       SVENTT_TRACE_LDS_BYTES
+                 : 0;
+#if defined(SVENTT_TRACE)
+  static constexpr size_t TRACE_LDS_WORD = ((size_t)1 << LOGT) + ((TW_LDS_WORDS + 1u) & ~1u);
+  __device__ __forceinline__ static void trace_stamp(u64 *lds, int slot) {
+    const u64 tm = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63u) == 0) lds[TRACE_LDS_WORD + (threadIdx.x >> 6) * TRACE_SLOTS + slot] = tm;
+  }
+#define SVENTT_STAMP(lds, slot) trace_stamp(lds, slot)
+#else
+#define SVENTT_STAMP(lds, slot) ((void)0)
+#endif
 
   // ---- which thread holds which radix set ----------------------------------------------
   // Set number s (LOGT - k bits) names the 2^k elements I = ((s >> lo) << hi) | (v << lo) |
@@ -461,7 +482,10 @@ struct TileNTT {
       s_low[g] = s & ((1u << lo) - 1u);
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
+    constexpr int TR = 6 * ((MODE == MODE_FWD) ? SI : NSTEPS - 1 - SI);  // (trace slots of this step)
+    SVENTT_STAMP(lds, TR + 0);
     // the table prefix the middle steps read from LDS: asked for first, so that it arrives first
+    // (asking for the data first instead was measured: 199.0 against 196.1 us, profiles/r02/asm_stages_ab.txt)
     constexpr bool tw_fill = TW_LDS_WORDS > 0 && from_hbm;
     u64 twl[TW_LDS_PER_THREAD > 0 ? TW_LDS_PER_THREAD : 1];
     if constexpr (tw_fill) {
@@ -480,6 +504,7 @@ struct TileNTT {
       w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
     }
     exchange_sync<SYNC>();
+    SVENTT_STAMP(lds, TR + 1);
     if constexpr (tw_in_lds && TWW == 1) {  // (two-word twiddles are read group by group: stages_asm)
       w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low, lds);
       w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
@@ -503,6 +528,7 @@ struct TileNTT {
         for (int v = 0; v < R; ++v) x[g * R + v] = lds[P0 ^ lds_phys((u32)v << lo)];
       }
     }
+    SVENTT_STAMP(lds, TR + 2);
     if constexpr (tw_fill) {
       // (the data loads above are in flight; every wave is waiting for them anyway)
 #pragma unroll
@@ -515,6 +541,10 @@ struct TileNTT {
       // exchanges inside its wave.  inverse: the next steps are wave-local, no barrier comes in time.
       if constexpr (MODE == MODE_INV || sync_before<1>() != SYNC_GROUP) __syncthreads();
     }
+#if defined(SVENTT_TRACE)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the data (and everything asked for before it) is here
+    SVENTT_STAMP(lds, TR + 3);
+#endif
     if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), zr, c);
     // ---- k fused stages ------------------------------------------------------
     TwistFactors f0;
@@ -528,6 +558,7 @@ struct TileNTT {
     // more to the unmerged stores than they gain, so they keep storing at the end.
     constexpr bool early = SVENTT_EARLY_STORES != 0 && to_hbm && COL && MODE == MODE_INV;
     stages_asm<k, LO, lo, 0, twist_out, multiply_out, early>(a, t, lds, x, I0, s_low, w0, w1, f0, o0, zr, c);
+    SVENTT_STAMP(lds, TR + 4);
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
       if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, zr, c);
@@ -562,6 +593,7 @@ struct TileNTT {
         for (int v = 0; v < R; ++v) lds[P0 ^ lds_phys((u32)v << lo)] = x[g * R + v];
       }
     }
+    SVENTT_STAMP(lds, TR + 5);
   }
 
   // A lowest step's twiddles with index 0 are omega^0 and their butterflies multiply by nothing
