@@ -3,9 +3,11 @@
 // PageMemory<T>(length, allocate_huge_pages) keeps the interface of the
 // reference's class of the same name (include/sventt/vector.hpp:61-168 there):
 // page-aligned anonymous memory, size()/data()/operator[]/at()/begin()/end(),
-// reset().  On this build it is ordinary host memory; NTT::compute_* accepts it
-// (the engine stages host buffers through the device) as well as device
-// pointers.  AuxiliaryVector / FakeByteVector / pointer_utility keep the interface of
+// reset().  On this build it is host memory that NTT::compute_* accepts (the engine
+// stages host buffers through the device) as well as device pointers; mappings of up to
+// 4 GiB are page-locked through the engine (sventt_host_register, include/sventt_hip.h) so
+// that the staging copies run at the PCIe rate -- best effort, SVENTT_PIN_HOST=0 turns it
+// off, =1 lifts the size limit.  AuxiliaryVector / FakeByteVector / pointer_utility keep the interface of
 // the reference's byte blob (vector.hpp:24-48,170-254 there) for code that drives a
 // kernel_type directly (prepare_forward(vec), compute_forward(dst, src, cursor)); on
 // this build the blob holds plan records (plan_handle.hpp), the twiddle tables
@@ -19,7 +21,15 @@
 #include <new>
 #include <stdexcept>
 
+#include <cstdlib>
+
 #include <sys/mman.h>
+
+// (weak: a program that only uses the containers need not link the engine)
+extern "C" {
+int sventt_host_register(void *host, std::size_t bytes) __attribute__((weak));
+int sventt_host_unregister(void *host) __attribute__((weak));
+}
 
 namespace sventt {
 
@@ -32,14 +42,30 @@ private:
   size_type length{};
   size_type mapped_bytes{};
   value_type *base{};
+  bool pinned{};
 
   void release(void) {
     if (base != nullptr) {
+      if (pinned && sventt_host_unregister != nullptr) {
+        (void)sventt_host_unregister(base);
+      }
       munmap(base, mapped_bytes);
     }
     base = nullptr;
     mapped_bytes = 0;
     length = 0;
+    pinned = false;
+  }
+
+  static bool want_pinning(const size_type bytes) {
+    if (sventt_host_register == nullptr) {
+      return false;
+    }
+    const char *const e{std::getenv("SVENTT_PIN_HOST")};
+    if (e != nullptr) {
+      return std::atoi(e) != 0;
+    }
+    return bytes <= (size_type{4} << 30);
   }
 
 public:
@@ -53,9 +79,10 @@ public:
   PageMemory &operator=(const PageMemory &) = delete;
 
   PageMemory(PageMemory &&that) noexcept
-      : length{that.length}, mapped_bytes{that.mapped_bytes}, base{that.base} {
+      : length{that.length}, mapped_bytes{that.mapped_bytes}, base{that.base}, pinned{that.pinned} {
     that.base = nullptr;
     that.length = that.mapped_bytes = 0;
+    that.pinned = false;
   }
 
   PageMemory &operator=(PageMemory &&that) noexcept {
@@ -64,8 +91,10 @@ public:
       length = that.length;
       mapped_bytes = that.mapped_bytes;
       base = that.base;
+      pinned = that.pinned;
       that.base = nullptr;
       that.length = that.mapped_bytes = 0;
+      that.pinned = false;
     }
     return *this;
   }
@@ -105,6 +134,7 @@ public:
     base = static_cast<value_type *>(p);
     mapped_bytes = bytes;
     length = len;
+    pinned = want_pinning(bytes) && sventt_host_register(p, bytes) == 0;
   }
 
   value_type &operator[](const size_type index) { return base[index]; }

@@ -284,6 +284,15 @@ int sventt_transpose(uint64_t *dst, const uint64_t *src, uint64_t src_rows,
 /* transpose(dst, dim): square, in place (transposition/sve/in-register.hpp:215-375). */
 int sventt_transpose_inplace(uint64_t *dst, uint64_t dim, void *stream);
 
+/* Page-lock (pin) a caller-owned host buffer so that the host-pointer path of
+ * sventt_forward/sventt_inverse moves it at the PCIe rate (N = 2^24: 4.96 ms per
+ * transform against 6.01 ms from pageable memory).  The reference keeps its data in
+ * PageMemory<T> (vector.hpp:61-168: mmap'ed, optionally huge pages); the facade's
+ * PageMemory registers its mapping with these two, best effort.  Unregister before the
+ * memory is unmapped or freed. */
+int sventt_host_register(void *host, size_t bytes);
+int sventt_host_unregister(void *host);
+
 const char *sventt_last_error(void);
 const char *sventt_version(void);
 

@@ -62,6 +62,8 @@ SYMBOLS = {
     "sventt_forward_multiply": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sventt_transpose": (_int, [_vp, _vp, _u64, _u64, _u64, _u64, _vp]),
     "sventt_transpose_inplace": (_int, [_vp, _u64, _vp]),
+    "sventt_host_register": (_int, [_vp, ctypes.c_size_t]),
+    "sventt_host_unregister": (_int, [_vp]),
     "sventt_last_error": (ctypes.c_char_p, []),
     "sventt_version": (ctypes.c_char_p, []),
 }

@@ -693,6 +693,20 @@ int sventt_transpose_inplace(uint64_t *dst, uint64_t dim, void *stream_) {
   return SVENTT_OK;
 }
 
+int sventt_host_register(void *host, size_t bytes) {
+  if (!host || bytes == 0) return fail(SVENTT_ERR_INVALID_ARGUMENT, "sventt_host_register: empty buffer");
+  int rc = check_device();
+  if (rc) return rc;
+  HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  return SVENTT_OK;
+}
+
+int sventt_host_unregister(void *host) {
+  if (!host) return fail(SVENTT_ERR_INVALID_ARGUMENT, "sventt_host_unregister: null pointer");
+  HIP_TRY(hipHostUnregister(host));
+  return SVENTT_OK;
+}
+
 const char *sventt_last_error(void) { return g_last_error.c_str(); }
 const char *sventt_version(void) { return "sventt-hip 0.1 (gfx950)"; }
 

@@ -101,9 +101,11 @@ bool run_rank(const Case &c, int rank, Shared &shared, const std::vector<std::ui
   HIP_OK(hipMalloc(&d_recv, bytes));
   HIP_OK(hipMalloc(&d_back, bytes));
   HIP_OK(hipMemcpy(d_src, slab.data(), bytes, hipMemcpyHostToDevice));
-  HIP_OK(hipMemset(d_dst, 0x55, bytes));
   hipStream_t stream{};
   HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  // (fills go on the transform's own stream: it does not synchronise with the null stream, and a
+  // null-stream hipMemset still running when the last pass writes its output would overwrite it)
+  HIP_OK(hipMemsetAsync(d_dst, 0x55, bytes, stream));
   Loopback loop{&shared, rank};
   const sventt_transport transport{&loop, &loopback_all_to_all};
 
@@ -124,7 +126,7 @@ bool run_rank(const Case &c, int rank, Shared &shared, const std::vector<std::ui
       why = "forward modified its source";
       ok = false;
     }
-    HIP_OK(hipMemset(d_back, 0x55, bytes));
+    HIP_OK(hipMemsetAsync(d_back, 0x55, bytes, stream));
     if (sventt_sharded_inverse_transport(cols, rows, &transport, d_back, d_dst, d_work, d_recv, c.chunks, stream)) {
       why = std::string{"inverse: "} + sventt_last_error();
       return false;

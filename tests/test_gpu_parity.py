@@ -575,3 +575,30 @@ def test_error_behaviour(eng):
     x = torch.zeros(1 << 10, dtype=torch.int64, device="cuda")
     with pytest.raises(eng.SventtError):  # std::logic_error
         fwd_only.compute_inverse(x)
+
+
+def test_registered_host_buffers(eng, port):
+    """sventt_host_register / sventt_host_unregister (what the facade's PageMemory does with its
+    mapping): the host-pointer path gives the oracle's result from page-locked buffers too, the
+    pair can be repeated, and a null pointer is refused."""
+    import ctypes
+    from sve_ntt_amd import _lib
+    lib = _lib.load()
+    m = 1 << 18
+    src = port.fill_splitmix(m, 77, P)
+    want = port.forward(src, P, G)
+    buf = np.empty(2 * m, dtype=np.uint64)
+    buf[:m] = src
+    buf[m:] = 0x5555555555555555
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    for _ in range(2):
+        assert lib.sventt_host_register(ctypes.c_void_p(buf.ctypes.data), buf.nbytes) == 0, lib.sventt_last_error()
+        try:
+            ntt.compute_forward(buf[m:], buf[:m])
+            assert np.array_equal(buf[m:], want)
+            ntt.compute_inverse(buf[m:])
+            assert np.array_equal(buf[m:], src)
+        finally:
+            assert lib.sventt_host_unregister(ctypes.c_void_p(buf.ctypes.data)) == 0
+    assert lib.sventt_host_register(None, 64) == _lib.SVENTT_ERR_INVALID_ARGUMENT
+    assert lib.sventt_host_unregister(None) == _lib.SVENTT_ERR_INVALID_ARGUMENT

@@ -24,3 +24,14 @@ pd = torch.empty_like(ps).pin_memory()
 t = timeit(lambda: ntt.compute_forward(pd.data_ptr(), ps.data_ptr()))
 print("pinned host buffers:   %.2f ms per transform, %.2e elem/s" % (t * 1e3, n / t))
 assert np.array_equal(pd.numpy().view(np.uint64), dst)
+
+# what the facade's PageMemory does: the caller's own (numpy) buffers page-locked through the engine
+import ctypes
+from sve_ntt_amd import _lib
+lib = _lib.load()
+for arr in (src, dst):
+    assert lib.sventt_host_register(ctypes.c_void_p(arr.ctypes.data), arr.nbytes) == 0
+t = timeit(lambda: ntt.compute_forward(dst, src))
+print("registered (sventt_host_register) buffers: %.2f ms per transform, %.2e elem/s" % (t * 1e3, n / t))
+for arr in (src, dst):
+    assert lib.sventt_host_unregister(ctypes.c_void_p(arr.ctypes.data)) == 0
