@@ -108,6 +108,7 @@ struct Tuning {
   int max_col_logl;
   bool fine;  // SVENTT_FINE=0 disables the E = 4 tiles for small transforms
   int fine_max_total_log2;  // SVENTT_FINE_MAX_LOG2: largest n*batch (log2) that runs on them
+  int fine_max_two_pass_log2;  // ... when the transform takes two passes (the same variable sets both)
   int twist_lo_log2;        // SVENTT_TWIST_LO_LOG2: cap on the low twist table (0: balanced split)
 };
 inline const Tuning &tuning(void) {
@@ -120,6 +121,9 @@ inline const Tuning &tuning(void) {
     x.fine = fe ? (std::atoi(fe) != 0) : true;
     const char *fm = std::getenv("SVENTT_FINE_MAX_LOG2");
     x.fine_max_total_log2 = fm ? std::atoi(fm) : MAX_FINE_TOTAL_LOG2;
+    // r02: at n*batch = 2^21 the 2^12/2^13-element tiles win for two-pass transforms (2^21: 35.0 against
+    // 38.4 us, 2^17 x 16: 30.4 against 33.1), the fine ones for single rows (2^10 x 2048: 14.9 against 16.2)
+    x.fine_max_two_pass_log2 = fm ? std::atoi(fm) : MAX_FINE_TOTAL_LOG2 - 1;
     const char *tl = std::getenv("SVENTT_TWIST_LO_LOG2");
     // r01: a low table of 2^10 entries (8 KiB) stays in the vector L1 whatever the lanes ask
     // for; the balanced split (2^12..2^14 entries) cost the column pass 2 % at M = 2^24 and
@@ -392,7 +396,9 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   std::vector<int> cols;
   int row = 0;
   // small totals run on the fine (E = 4) tiles, provided they cover the requested split
-  pl.fine = tuning().fine && pl.arith == ARITH_MONT && pl.total <= (1ull << tuning().fine_max_total_log2) &&
+  pl.fine = tuning().fine && pl.arith == ARITH_MONT &&
+            pl.total <= (1ull << (logn <= MAX_FINE_ROW_LOGL ? tuning().fine_max_total_log2
+                                                           : tuning().fine_max_two_pass_log2)) &&
             logn <= MAX_FINE_COL_LOGL + MAX_FINE_ROW_LOGL &&
             // 2^12 and 2^13 are one pass on the 2^12/2^13-element tiles, two on the fine ones
             (n0_log2 != 0 || logn <= MAX_FINE_ROW_LOGL || logn > MAX_ROW_LOGL);

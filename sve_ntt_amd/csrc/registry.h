@@ -73,7 +73,7 @@ using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
                             typename DefaultSteps<LOGL>::type, ARITH>;
 
 // Fine tiles for transforms too small to fill the chip with 2^12-element tiles
-// (n * batch <= 2^21, e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
+// (n * batch <= 2^20, or 2^21 for single-pass rows; e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
 // elements per thread in radix-4 steps, 2^8..2^11-element tiles -- four times the
 // workgroups and a quarter of the serial work per thread; these runs are latency
 // bound, not bandwidth bound.

@@ -106,7 +106,11 @@ def test_plan_shapes():
     assert [(x["kind"], x["logl"]) for x in s] == [(1, 8), (0, 9)]
     # ... on the fine tiles (E = 4): 128 column tiles of 4 columns, one row per tile
     assert [(x["loge"], x["f0"], x["logt"], x["grid"]) for x in s] == [(2, 2, 10, 128), (2, 0, 9, 256)]
-    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 21))
+    # two-pass transforms: fine tiles up to n*batch = 2^20, the 2^12/2^13-element tiles from 2^21 on
+    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 20))
+    assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 17, batch=8))
+    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 21))
+    assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 17, batch=16))
     assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 22))
     assert all(x["loge"] == 2 for x in simlib.plan_shape(P, G, 1 << 10, batch=1 << 11))
     assert all(x["loge"] == 4 for x in simlib.plan_shape(P, G, 1 << 10, batch=1 << 12))
