@@ -12,11 +12,11 @@ hi = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 print("%-6s %-58s %10s %12s %8s" % ("n", "plan", "us", "elem/s", "GB/s"))
 for log2n in range(lo, hi + 1):
     n = 1 << log2n
-    ntt = eng.NTT(eng.BASELINE_MODULUS, n)
+    ntt = eng.NTT(eng.BASELINE_MODULUS, n, device_pointers=True)
     x = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device="cuda")
     y = torch.empty_like(x)
-    reps = max(10, min(400, (1 << 27) // n))
-    for _ in range(5):
+    reps = max(50, min(2000, (1 << 31) // n))  # ~25 ms of work at least: steady-state clocks (tools/clock_ramp.py)
+    for _ in range(reps):
         ntt.compute_forward(y, x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
