@@ -35,19 +35,38 @@ def needs_build() -> bool:
 
 
 def regenerate_stage_asm() -> None:
-    """stage_asm.inc is generated (and committed); refresh it when its generator is newer."""
+    """stage_asm.inc is generated (and committed); refresh it when its generator is newer.  Only
+    called on the way to a compilation; the file is replaced atomically, and left alone when the
+    generator's output is what it already holds (several ranks or test workers may import the
+    package at once, and an installed tree may be read-only)."""
     gen = os.path.join(CSRC, "gen_stage_asm.py")
     inc = os.path.join(CSRC, "stage_asm.inc")
-    if not os.path.exists(inc) or os.path.getmtime(inc) < os.path.getmtime(gen):
-        text = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
-        with open(inc, "w") as f:
-            f.write(text)
+    if os.path.exists(inc) and os.path.getmtime(inc) >= os.path.getmtime(gen):
+        return
+    text = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
+    try:
+        with open(inc) as f:
+            if f.read() == text:
+                os.utime(inc)  # same content: only remember that it was checked
+                return
+    except OSError:
+        pass
+    tmp = f"{inc}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, inc)
+
+
+def _stage_asm_is_stale() -> bool:
+    gen = os.path.join(CSRC, "gen_stage_asm.py")
+    inc = os.path.join(CSRC, "stage_asm.inc")
+    return not os.path.exists(inc) or os.path.getmtime(inc) < os.path.getmtime(gen)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    regenerate_stage_asm()
-    if not force and not needs_build():
+    if not force and not needs_build() and not _stage_asm_is_stale():
         return LIB
+    regenerate_stage_asm()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 

@@ -10,10 +10,11 @@ namespace sventt_hip {
 using KernelEntry = KernelEntryT<hipError_t, hipStream_t>;
 
 // arith: ARITH_MONT / ARITH_GOLD / ARITH_SHOUP (field64.h); the last two have E = 16 tiles only
+// two_level: the TWOLVL variant of a column tile (tile_ntt.h)
 const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge,
-                               int arith = ARITH_MONT);
-const KernelEntry *find_kernel_gold(int kind, int logl, int dir, int flag, int f0, int loge);    // kernels_gold.hip
-const KernelEntry *find_kernel_shoup(int kind, int logl, int dir, int flag, int f0, int loge);   // kernels_shoup.hip
+                               int arith = ARITH_MONT, int two_level = 0);
+const KernelEntry *find_kernel_gold(int kind, int logl, int dir, int flag, int f0, int loge, int two_level);    // kernels_gold.hip
+const KernelEntry *find_kernel_shoup(int kind, int logl, int dir, int flag, int f0, int loge, int two_level);   // kernels_shoup.hip
 
 hipError_t launch_pointwise(u64 *dst, const u64 *a, const u64 *b, u64 count, const Field &f,
                             u64 r2, hipStream_t stream);

@@ -175,14 +175,15 @@ hipError_t launch_transpose_inplace(u64 *m, u64 dim, hipStream_t stream) {
 }
 
 // ---- registry -------------------------------------------------------------------
-const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge, int arith) {
+const KernelEntry *find_kernel(int kind, int logl, int dir, int flag, int f0, int loge, int arith,
+                               int two_level) {
   switch (arith) {
     case ARITH_MONT:
-      return find_kernel_in_registry<KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge);
+      return find_kernel_in_registry<KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge, two_level);
     case ARITH_GOLD:
-      return find_kernel_gold(kind, logl, dir, flag, f0, loge);
+      return find_kernel_gold(kind, logl, dir, flag, f0, loge, two_level);
     case ARITH_SHOUP:
-      return find_kernel_shoup(kind, logl, dir, flag, f0, loge);
+      return find_kernel_shoup(kind, logl, dir, flag, f0, loge, two_level);
   }
   return nullptr;
 }

@@ -4,8 +4,8 @@
 
 namespace sventt_hip {
 
-const KernelEntry *find_kernel_gold(int kind, int logl, int dir, int flag, int f0, int loge) {
-  return find_arith_kernel_in_registry<ARITH_GOLD, KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge);
+const KernelEntry *find_kernel_gold(int kind, int logl, int dir, int flag, int f0, int loge, int two_level) {
+  return find_arith_kernel_in_registry<ARITH_GOLD, KernelEntry, HipLauncher>(kind, logl, dir, flag, f0, loge, two_level);
 }
 
 }  // namespace sventt_hip

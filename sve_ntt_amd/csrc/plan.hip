@@ -3,7 +3,6 @@
 // by plan_core.h (host-only).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types and enums only: librccl is dlopen'ed on first use, never linked
 
 #include <cstring>
 #include <mutex>
@@ -82,7 +81,8 @@ int realize(const std::vector<HostPass> &host, std::vector<DevicePass> &dev) {
   for (size_t i = 0; i < host.size(); ++i) {
     const HostPass &h = host[i];
     DevicePass &d = dev[i];
-    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge, h.arith);
+    d.kernel = find_kernel(h.kind, h.logl, h.inverse ? MODE_INV : MODE_FWD, h.flag ? 1 : 0, h.f0, h.loge, h.arith,
+                           h.two_level);
     if (!d.kernel) return fail(SVENTT_ERR_LOGIC, "no kernel instantiated for this pass shape");
     if (d.kernel->f0 != h.f0 || d.kernel->logt != h.logt)
       return fail(SVENTT_ERR_LOGIC, "planner and kernel registry disagree on the tile shape");
@@ -118,15 +118,6 @@ int finish_plan(sventt_plan *pl, int rc, const std::string &err, sventt_plan **o
   return SVENTT_OK;
 }
 
-int run_pass(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const u64 *src,
-             hipStream_t stream) {
-  const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[index];
-  const DevicePass &d = (inverse ? pl->inv : pl->fwd)[index];
-  const PassArgs a = make_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi);
-  HIP_TRY(d.kernel->launch(a, (u32)h.grid, stream));
-  return SVENTT_OK;
-}
-
 // device: if non-null, receives the ordinal of the device that owns the memory (-1: host)
 bool is_device_pointer(const void *p, int *device = nullptr) {
   hipPointerAttribute_t attr;
@@ -150,6 +141,20 @@ int check_current_device(const sventt_plan *pl) {
     return fail(SVENTT_ERR_INVALID_ARGUMENT,
                 "the plan was created on HIP device " + std::to_string(pl->device) +
                     " but the calling thread's current device is " + std::to_string(cur));
+  return SVENTT_OK;
+}
+
+// One pass launch.  Every entry point that launches on behalf of a plan comes through here or
+// through run_chunk / check_current_device itself: a launch from a thread whose current device is
+// not the plan's would read tables that live elsewhere.
+int run_pass(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const u64 *src,
+             hipStream_t stream) {
+  int rc = check_current_device(pl);
+  if (rc) return rc;
+  const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[index];
+  const DevicePass &d = (inverse ? pl->inv : pl->fwd)[index];
+  const PassArgs a = make_args(pl->host, h, dst, src, d.stage, d.twist_lo, d.twist_hi);
+  HIP_TRY(d.kernel->launch(a, (u32)h.grid, stream));
   return SVENTT_OK;
 }
 
@@ -295,8 +300,7 @@ uint64_t sventt_plan_pass_tiles_per_block(const sventt_plan *pl, int inverse, in
   if (!pl) return 0;
   const std::vector<HostPass> &passes = inverse ? pl->host.inv : pl->host.fwd;
   if (pass_index < 0 || (size_t)pass_index >= passes.size()) return 0;
-  const HostPass &h = passes[(size_t)pass_index];
-  return h.kind == KIND_COL ? (h.istride >> h.f0) : 0;
+  return pass_chunk_tiles(passes[(size_t)pass_index]);
 }
 
 int sventt_run_pass_chunk(const sventt_plan *pl, int inverse, int pass_index, uint64_t *dst,
@@ -306,6 +310,8 @@ int sventt_run_pass_chunk(const sventt_plan *pl, int inverse, int pass_index, ui
   const size_t npass = (inverse ? pl->inv : pl->fwd).size();
   if (pass_index < 0 || (size_t)pass_index >= npass)
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "pass index out of range");
+  int rc = check_current_device(pl);
+  if (rc) return rc;
   const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[(size_t)pass_index];
   const DevicePass &d = (inverse ? pl->inv : pl->fwd)[(size_t)pass_index];
   PassArgs a;
@@ -351,6 +357,7 @@ namespace {
 
 int run_chunk(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const u64 *src, u32 chunk,
               u32 nchunks, bool dst_compact, bool src_compact, hipStream_t stream) {
+  if (int rc = check_current_device(pl)) return rc;
   const HostPass &h = (inverse ? pl->host.inv : pl->host.fwd)[index];
   const DevicePass &d = (inverse ? pl->inv : pl->fwd)[index];
   PassArgs a;
@@ -366,7 +373,7 @@ int run_chunk(const sventt_plan *pl, bool inverse, size_t index, u64 *dst, const
 int check_shard_pair(const sventt_plan *cols, const sventt_plan *rows, bool inverse, u32 chunks) {
   if (!cols->host.sharded || cols->host.local_cols == 0)
     return fail(SVENTT_ERR_LOGIC, "`cols` is not a sharded column plan");
-  if (!rows->host.sharded || rows->host.local_cols != 0 || rows->host.nranks < 2)
+  if (!rows->host.sharded || rows->host.local_cols != 0 || rows->host.nranks < 1)
     return fail(SVENTT_ERR_LOGIC, "`rows` is not a sharded rows plan");
   if (cols->host.nranks != rows->host.nranks || cols->host.rank != rows->host.rank ||
       cols->host.f.N != rows->host.f.N || cols->host.total != rows->host.total)
@@ -376,7 +383,7 @@ int check_shard_pair(const sventt_plan *cols, const sventt_plan *rows, bool inve
   const HostPass &cp = (inverse ? cols->host.inv : cols->host.fwd)[0];
   const std::vector<HostPass> &rp = inverse ? rows->host.inv : rows->host.fwd;
   const HostPass &xp = inverse ? rp.back() : rp.front();  // the pass next to the exchange
-  if (chunks == 0 || (cp.istride >> cp.f0) % chunks != 0 || (xp.istride >> xp.f0) % chunks != 0)
+  if (chunks == 0 || pass_chunk_tiles(cp) % chunks != 0 || pass_chunk_tiles(xp) % chunks != 0)
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "chunks must divide the column tile counts of both plans");
   if (cols->host.total % ((u64)chunks * (u64)cols->host.nranks) != 0)
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "chunks do not divide the local data");
@@ -457,7 +464,14 @@ int sharded_transform(const sventt_plan *cols, const sventt_plan *rows, const sv
   return SVENTT_OK;
 }
 
-// RCCL, loaded on first use so that single-GPU users do not need the library
+// RCCL, loaded on first use so that single-GPU users need neither the library nor its headers: the
+// handful of types and values of <rccl/rccl.h> (nccl.h 2.x ABI) that the exchange uses are restated here.
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;    // ncclSuccess == 0
+typedef int ncclDataType_t;  // ncclUint64 == 5
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint64 = 5;
+
 struct Rccl {
   void *handle = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -578,6 +592,7 @@ int sventt_pointwise_multiply(const sventt_plan *pl, uint64_t *dst, const uint64
   if (!pl || !dst || !a || !b) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
   if (!pl->device_pointers && (!is_device_pointer(dst) || !is_device_pointer(a) || !is_device_pointer(b)))
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "pointwise multiply takes device pointers");
+  if (int rc = check_current_device(pl)) return rc;
   HIP_TRY(launch_pointwise(dst, a, b, count, pl->host.f, pl->host.r2,
                            static_cast<hipStream_t>(stream)));
   return SVENTT_OK;
@@ -592,6 +607,7 @@ int sventt_forward_multiply(const sventt_plan *pl, uint64_t *dst, const uint64_t
       (!is_device_pointer(dst) || !is_device_pointer(src) || !is_device_pointer(operand)))
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "the fused forward-multiply takes device pointers");
   if (operand == dst) return fail(SVENTT_ERR_INVALID_ARGUMENT, "operand must not alias dst");
+  if (int rc = check_current_device(pl)) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (pl->host.n == 1) {
     HIP_TRY(launch_montmul(dst, src, operand, 0, pl->host.total, pl->host.f, stream));
@@ -618,6 +634,7 @@ static int convert_domain(const sventt_plan *pl, uint64_t *dst, const uint64_t *
   if (!pl || !dst || !src) return fail(SVENTT_ERR_INVALID_ARGUMENT, "null argument");
   if (!pl->device_pointers && (!is_device_pointer(dst) || !is_device_pointer(src)))
     return fail(SVENTT_ERR_INVALID_ARGUMENT, "domain conversion takes device pointers");
+  if (int rc = check_current_device(pl)) return rc;
   HIP_TRY(launch_montmul(dst, src, nullptr, factor, count, pl->host.f, static_cast<hipStream_t>(stream)));
   return SVENTT_OK;
 }
@@ -697,13 +714,24 @@ int sventt_host_register(void *host, size_t bytes) {
   if (!host || bytes == 0) return fail(SVENTT_ERR_INVALID_ARGUMENT, "sventt_host_register: empty buffer");
   int rc = check_device();
   if (rc) return rc;
-  HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    // callers use this best-effort (PageMemory): do not leave HIP's per-thread sticky error behind,
+    // the next launch on this thread would report it as its own (launch_tile returns hipGetLastError)
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? SVENTT_ERR_ALLOC : SVENTT_ERR_HIP,
+                std::string("hipHostRegister: ") + hipGetErrorString(e));
+  }
   return SVENTT_OK;
 }
 
 int sventt_host_unregister(void *host) {
   if (!host) return fail(SVENTT_ERR_INVALID_ARGUMENT, "sventt_host_unregister: null pointer");
-  HIP_TRY(hipHostUnregister(host));
+  const hipError_t e = hipHostUnregister(host);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(SVENTT_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+  }
   return SVENTT_OK;
 }
 

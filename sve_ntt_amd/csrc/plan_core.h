@@ -33,6 +33,14 @@ struct HostPass {
   u64 block = 0;    // COL: M = L*S
   // gather/scatter passes of the sharded transform address the two sides differently
   u64 dst_istride = 0, dst_ostride = 0, src_istride = 0, src_ostride = 0;
+  // two-level passes (tile_ntt.h: TWOLVL; the sharded row transform's first pass when it is longer
+  // than the rank count): row i lies at (i >> row_split) * X_istride_hi + (i mod 2^row_split) * X_istride
+  int two_level = 0;
+  u32 row_split = 0;
+  u64 dst_istride_hi = 0, src_istride_hi = 0;
+  // sharded column pass: the columns of exchange chunk k of K are, in every run of chunk_period
+  // columns, the k-th K-th (0: one run, i.e. K contiguous column ranges) -- make_chunk_args
+  u64 chunk_period = 0;
   u64 grid = 0;
   int f0 = 0, logt = 0;
   int loge = REG_LOGE;  // elements per thread (log2): REG_LOGE, or FINE_LOGE for small totals
@@ -110,6 +118,7 @@ struct Tuning {
   int fine_max_total_log2;  // SVENTT_FINE_MAX_LOG2: largest n*batch (log2) that runs on them
   int fine_max_two_pass_log2;  // ... when the transform takes two passes (the same variable sets both)
   int twist_lo_log2;        // SVENTT_TWIST_LO_LOG2: cap on the low twist table (0: balanced split)
+  bool sharded_fuse;        // SVENTT_SHARDED_FUSE=0: the sharded row phase gathers in a pass of its own (r02)
 };
 inline const Tuning &tuning(void) {
   static const Tuning t = [] {
@@ -129,6 +138,8 @@ inline const Tuning &tuning(void) {
     // for; the balanced split (2^12..2^14 entries) cost the column pass 2 % at M = 2^24 and
     // 12 % at M = 2^27 (sharded, 8 ranks)
     x.twist_lo_log2 = tl ? std::atoi(tl) : 10;
+    const char *sf = std::getenv("SVENTT_SHARDED_FUSE");
+    x.sharded_fuse = sf ? (std::atoi(sf) != 0) : true;
     return x;
   }();
   return t;
@@ -201,6 +212,10 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
   ps.block = S << logl;
   ps.dst_istride = ps.src_istride = S;
   ps.dst_ostride = ps.src_ostride = ps.block;
+  ps.two_level = 0;
+  ps.row_split = 0;
+  ps.dst_istride_hi = ps.src_istride_hi = 0;
+  ps.chunk_period = 0;
   ps.twist_col_offset = col_offset;
   ps.loge = pl.fine ? FINE_LOGE : REG_LOGE;
   ps.arith = pl.arith;
@@ -450,6 +465,37 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   return PLAN_OK;
 }
 
+// How one rank's share of the ROW phase of the sharded six-step is cut into passes (both sharded
+// planners call this: they must agree on what an exchange chunk is).  The row transform has length
+// C = 2^logc and arrives as G = 2^logg pieces of C / G columns, one from every rank.  It runs as the
+// ordinary plan of a length-C transform whose first column pass is at least G long: the piece index
+// is the top logg bits of that pass's row index, so the pass reads the pieces where they were
+// received and the gather costs no sweep of its own (kernel/recursive.hpp:61-75 of the reference:
+// one column phase, one row phase).
+//   cols[0] == logg: one row per piece, a plain strided pass;
+//   cols[0]  > logg: 2^(cols[0] - logg) rows per piece, a two-level pass (TileNTT's TWOLVL).
+// r02 always gathered in a length-G pass of its own (N = 2^30 on 8 ranks: col 2^3 | col 2^3 | row 2^13,
+// four sweeps per rank with the column phase; now col 2^6 | row 2^13, three).
+// A single rank (logg = 0; the whole pipeline on one GPU, exchange with itself) has one piece, which
+// IS the row: its first pass is two-level only to run the same code as the multi-rank plans.
+inline int sharded_row_split(int logc, int logg, std::vector<int> &cols, int &row, bool &two_level,
+                             std::string &err) {
+  int rc = choose_split(logc, 0, cols, row, err);
+  if (rc) return rc;
+  two_level = false;
+  bool ok = tuning().sharded_fuse && !cols.empty() && cols[0] >= logg;
+  if (ok && cols[0] > logg) {
+    const int f0 = registry_col_f0(cols[0], logc - cols[0], tuning().col_slim);
+    ok = two_level = f0 >= 0 && registry_has_two_level(cols[0], f0);
+  }
+  if (!ok && logg > 0) rc = choose_split(logc, (u32)logg, cols, row, err);  // a gather pass of its own, then the rest
+  if (!rc && cols.empty()) {
+    err = "rows too short for a column pass next to the exchange";  // (one rank, C <= 2^13)
+    rc = PLAN_ERR_INVALID_ARGUMENT;
+  }
+  return rc;
+}
+
 // One rank's column pass of the sharded six-step (include/sventt_hip.h).
 inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int rank, int nranks,
                               u32 flags, std::string &err) {
@@ -460,7 +506,7 @@ inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int
     return PLAN_ERR_INVALID_ARGUMENT;
   }
   const int logn = ilog2_u64(n);
-  if (r_log2 == 0 || (int)r_log2 >= logn || (int)r_log2 > MAX_COL_LOGL) {
+  if (r_log2 == 0 || (int)r_log2 >= logn || (int)r_log2 > tuning().max_col_logl) {
     err = "r_log2 out of range";
     return PLAN_ERR_INVALID_ARGUMENT;
   }
@@ -481,17 +527,30 @@ inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int
   pl.total = pl.local_cols << r_log2;
   const u64 ninv = h_invmod(n % p, p);
   const u64 off = pl.local_cols * (u64)rank;
+  // what an exchange chunk is depends on the first pass of the row phase (make_chunk_args)
+  u64 chunk_period = 0;
+  const int logc = logn - (int)r_log2, logg = ilog2_u64((u64)nranks);
+  if (logg < logc && logg <= (int)r_log2) {
+    std::vector<int> cols;
+    int row = 0;
+    bool two_level = false;
+    std::string ignored;
+    if (sharded_row_split(logc, logg, cols, row, two_level, ignored) == PLAN_OK && cols[0] > logg)
+      chunk_period = C >> cols[0];
+  }
   if (flags & PLAN_FORWARD) {
     pl.fwd.emplace_back();
     if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_COL, (int)r_log2, pl.local_cols, false, true, 1,
                              off, logn, err)))
       return rc;
+    pl.fwd.back().chunk_period = chunk_period;
   }
   if (flags & PLAN_INVERSE) {
     pl.inv.emplace_back();
     if ((rc = make_host_pass(pl, pl.inv.back(), KIND_COL, (int)r_log2, pl.local_cols, true, true,
                              ninv, off, logn, err)))
       return rc;
+    pl.inv.back().chunk_period = chunk_period;
   }
   return PLAN_OK;
 }
@@ -499,20 +558,20 @@ inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int
 // Row phase of the sharded six-step on one rank (include/sventt_hip.h): the rank
 // owns R/nranks rows of length C = nranks * Cl, delivered by the all-to-all as
 // nranks pieces per row: piece s of local row q sits at recv[s][q][0..Cl).
-// Forward = COL(nranks, S = Cl) reading that layout and writing whole rows,
-// then the ordinary passes of a length-Cl transform over the R/nranks * nranks
-// runs.  Inverse = the mirror, the last pass scattering back into piece layout.
+// Forward = the passes of a length-C transform over the rank's R/nranks rows
+// (sharded_row_split), the first of which reads that layout and writes whole rows.
+// Inverse = the mirror, the last pass scattering back into piece layout.
 // Never scales: the 1/n of the inverse rides on the column phase.
 inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int rank,
                                    int nranks, u32 flags, std::string &err) {
   int rc = validate_field(p, g, n, err);
   if (rc) return rc;
-  if (nranks < 2 || rank < 0 || rank >= nranks || !is_pow2((u64)nranks)) {
-    err = "rank/nranks invalid (nranks must be a power of two >= 2)";
+  if (nranks < 1 || rank < 0 || rank >= nranks || !is_pow2((u64)nranks)) {
+    err = "rank/nranks invalid (nranks must be a power of two)";
     return PLAN_ERR_INVALID_ARGUMENT;
   }
   const int logn = ilog2_u64(n), logg = ilog2_u64((u64)nranks);
-  if (r_log2 == 0 || (int)r_log2 >= logn || (int)r_log2 > MAX_COL_LOGL || logg > (int)r_log2 ||
+  if (r_log2 == 0 || (int)r_log2 >= logn || (int)r_log2 > tuning().max_col_logl || logg > (int)r_log2 ||
       logg > MAX_COL_LOGL) {
     err = "r_log2 out of range";
     return PLAN_ERR_INVALID_ARGUMENT;
@@ -534,14 +593,26 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
   pl.nranks = nranks;
   std::vector<int> cols;
   int row = 0;
-  if ((rc = choose_split(logcl, 0, cols, row, err))) return rc;
+  bool two_level = false;
+  if ((rc = sharded_row_split(logc, logg, cols, row, two_level, err))) return rc;
+  // the pass next to the exchange: row i = s * Lc + i' of a block is row i' of piece s
+  const int lc_log = cols[0] - logg;
+  auto piece_side = [&](HostPass &ps, u64 &istride, u64 &istride_hi, u64 &ostride, u64 &other_hi) {
+    const u64 S = ps.istride;
+    if (lc_log > 0 && !two_level) return;  // one rank, no two-level tile of this shape: the piece is the row
+    ostride = Cl;  // local row q
+    if (lc_log == 0) {
+      istride = Rl * Cl;  // piece s
+    } else {
+      ps.two_level = 1;
+      ps.row_split = (u32)lc_log;
+      istride = S;
+      istride_hi = Rl * Cl;
+      other_hi = S << lc_log;  // the ordinary side, in two-level form
+    }
+  };
   if (flags & PLAN_FORWARD) {
-    pl.fwd.emplace_back();
-    HostPass &gp = pl.fwd.back();
-    if ((rc = make_host_pass(pl, gp, KIND_COL, logg, Cl, false, true, 1, 0, logc, err))) return rc;
-    gp.src_istride = Rl * Cl;  // piece s
-    gp.src_ostride = Cl;       // local row q
-    int rem = logcl;
+    int rem = logc;
     for (size_t i = 0; i < cols.size(); ++i) {
       pl.fwd.emplace_back();
       rem -= cols[i];
@@ -551,6 +622,8 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
     }
     pl.fwd.emplace_back();
     if ((rc = make_host_pass(pl, pl.fwd.back(), KIND_ROW, row, 1, false, false, 1, 0, 0, err))) return rc;
+    HostPass &gp = pl.fwd.front();
+    piece_side(gp, gp.src_istride, gp.src_istride_hi, gp.src_ostride, gp.dst_istride_hi);
   }
   if (flags & PLAN_INVERSE) {
     pl.inv.emplace_back();
@@ -563,11 +636,8 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
         return rc;
       rem += cols[k];
     }
-    pl.inv.emplace_back();
     HostPass &sp = pl.inv.back();
-    if ((rc = make_host_pass(pl, sp, KIND_COL, logg, Cl, true, true, 1, 0, logc, err))) return rc;
-    sp.dst_istride = Rl * Cl;
-    sp.dst_ostride = Cl;
+    piece_side(sp, sp.dst_istride, sp.dst_istride_hi, sp.dst_ostride, sp.src_istride_hi);
   }
   return PLAN_OK;
 }
@@ -585,7 +655,14 @@ inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, cons
   a.ostride = ps.dst_ostride;
   a.src_istride = ps.src_istride;
   a.src_ostride = ps.src_ostride;
+  a.istride_hi = ps.dst_istride_hi;
+  a.src_istride_hi = ps.src_istride_hi;
+  a.row_split = ps.row_split;
   a.tiles_per_outer = (ps.kind == KIND_COL) ? (u32)(ps.istride >> ps.f0) : 0;
+  a.ct_first = 0;
+  a.run_shift = 31;  // one run
+  a.run_period = 0;
+  a.compact = 0;
   a.grid = (u32)ps.grid;
   a.twist_lo = twist_lo;
   a.twist_hi = twist_hi;
@@ -595,36 +672,55 @@ inline PassArgs make_args(const HostPlan &pl, const HostPass &ps, u64 *dst, cons
   return a;
 }
 
-// The same pass restricted to chunk `chunk` of `nchunks` equal column ranges of every
-// block.  A "compact" side is a buffer that holds only that chunk's columns: its
-// strides shrink by nchunks and its column index restarts at 0.  (The pipelined
-// all-to-all of the sharded transform: column pass chunk -> exchange chunk -> gather
+// Column tiles per run of a column pass (0 for a row pass): the number of exchange chunks must
+// divide it (make_chunk_args).
+inline u64 pass_chunk_tiles(const HostPass &ps) {
+  if (ps.kind != KIND_COL) return 0;
+  return (ps.chunk_period ? ps.chunk_period : ps.istride) >> ps.f0;
+}
+
+// The same pass restricted to chunk `chunk` of `nchunks`.  A chunk is the `chunk`-th of nchunks equal
+// column ranges of every RUN of the block's columns; a run is the whole block (ps.chunk_period == 0)
+// or chunk_period columns of it (the sharded column pass when the row phase starts with a two-level
+// pass: that pass needs, for its column c, the columns c + i' * period of every received piece, so a
+// chunk must hold all of them).  A "compact" side is a buffer that holds only the chunk's columns,
+// run after run: its strides shrink by nchunks and tile ct of the launch sits at column ct * T.
+// (The pipelined all-to-all of the sharded transform: column pass chunk -> exchange chunk -> gather
 // chunk.)  Returns the launch size in `grid`.
 inline int make_chunk_args(const HostPlan &pl, const HostPass &ps, u64 *dst, const u64 *src,
                            const u64 *stage, const u64 *twist_lo, const u64 *twist_hi, u32 chunk,
                            u32 nchunks, bool dst_compact, bool src_compact, PassArgs &a, u32 &grid,
                            std::string &err) {
   a = make_args(pl, ps, dst, src, stage, twist_lo, twist_hi);
-  const u64 tiles_per_block = ps.istride >> ps.f0;
-  if (ps.kind != KIND_COL || nchunks == 0 || chunk >= nchunks || tiles_per_block % nchunks != 0) {
+  const u64 period_tiles = pass_chunk_tiles(ps);
+  if (ps.kind != KIND_COL || nchunks == 0 || chunk >= nchunks || period_tiles % nchunks != 0) {
     err = "pass cannot be split into that many column chunks";
     return PLAN_ERR_INVALID_ARGUMENT;
   }
-  const u64 tpc = tiles_per_block / nchunks;
+  const u64 period_cols = ps.chunk_period ? ps.chunk_period : ps.istride;
+  const u64 run_tiles = period_tiles / nchunks, runs = ps.istride / period_cols;
+  if (!is_pow2(run_tiles) || period_cols >> 32) {
+    err = "pass cannot be split into that many column chunks";
+    return PLAN_ERR_INVALID_ARGUMENT;
+  }
+  const u64 tpc = run_tiles * runs;
   const u64 launch = (pl.total / ps.block) * tpc;
-  const u32 first_col = (u32)((ps.istride / nchunks) * chunk);
   a.tiles_per_outer = (u32)tpc;
-  a.ct_first = (u32)(tpc * chunk);
+  a.ct_first = (u32)(run_tiles * chunk);
+  a.run_shift = (u32)ilog2_u64(run_tiles);
+  a.run_period = (u32)period_cols;
   a.grid = (u32)launch;
   if (dst_compact) {
     a.istride /= nchunks;
+    a.istride_hi /= nchunks;
     a.ostride /= nchunks;
-    a.dst_col_bias = first_col;
+    a.compact |= 1u;
   }
   if (src_compact) {
     a.src_istride /= nchunks;
+    a.src_istride_hi /= nchunks;
     a.src_ostride /= nchunks;
-    a.src_col_bias = first_col;
+    a.compact |= 2u;
   }
   grid = (u32)launch;
   return PLAN_OK;
@@ -641,8 +737,9 @@ inline std::string describe_plan(const HostPlan &pl) {
     if (!first) d += " | ";
     first = false;
     if (p.kind == KIND_COL)
-      snprintf(buf, sizeof buf, "col 2^%d x T%d (stride %llu%s)", p.logl, 1 << p.f0,
-               (unsigned long long)p.istride, p.loge == FINE_LOGE ? ", E4" : "");
+      snprintf(buf, sizeof buf, "col 2^%d x T%d (stride %llu%s%s)", p.logl, 1 << p.f0,
+               (unsigned long long)p.istride, p.loge == FINE_LOGE ? ", E4" : "",
+               p.two_level ? ", two-level" : "");
     else
       snprintf(buf, sizeof buf, "row 2^%d (tile 2^%d%s)", p.logl, p.logt,
                p.loge == FINE_LOGE ? ", E4" : "");

@@ -12,7 +12,8 @@ namespace sventt_hip {
 enum : int { KIND_ROW = 0, KIND_COL = 1 };
 
 constexpr int MAX_ROW_LOGL = 13;  // longest transform one workgroup keeps on chip (64 KiB of LDS)
-constexpr int MAX_COL_LOGL = 11;  // longest strided column (x 8 columns = 128 KiB of LDS)
+constexpr int MAX_COL_LOGL = 11;  // longest strided column of the wide (T = 8) tiles: 128 KiB of LDS.  The slim
+                                  // (T = 4) tiles go to 2^12 (plan_core.h: Tuning::max_col_logl)
 
 // Step lists: radix-16 steps from the top stage down (E = 16 elements per
 // thread), remainder last.
@@ -53,9 +54,9 @@ constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
 template <int LOGL, int MODE, bool FLAG, int ARITH = ARITH_MONT>
 using RowTile =
     TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowSteps<LOGL>::type, ARITH>;
-template <int LOGL, int MODE, int ARITH = ARITH_MONT>
+template <int LOGL, int MODE, int ARITH = ARITH_MONT, bool TWOLVL = false>
 using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
-                        typename DefaultSteps<LOGL>::type, ARITH>;
+                        typename DefaultSteps<LOGL>::type, ARITH, TWOLVL>;
 
 // Narrow COL tiles (T = 8 whatever the column length) for blocks with fewer
 // columns than the wide tile wants; tiny tiles, only met at small n.
@@ -68,9 +69,14 @@ using ColTileNarrow = TileNTT<LOGL + NARROW_F0, NARROW_F0, LOGL, REG_LOGE, MODE,
 // TileNTT::locate lets one L2 merge the two halves of a 64-byte line): half the
 // LDS of the T = 8 tile, so two workgroups share a CU.
 constexpr int SLIM_F0 = 2;
-template <int LOGL, int MODE, int ARITH = ARITH_MONT>
+template <int LOGL, int MODE, int ARITH = ARITH_MONT, bool TWOLVL = false>
 using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
-                            typename DefaultSteps<LOGL>::type, ARITH>;
+                            typename DefaultSteps<LOGL>::type, ARITH, TWOLVL>;
+// Two-level variants of both (tile_ntt.h: TWOLVL): the first pass of the sharded row transform when it
+// is longer than the rank count, i.e. the gather of the received pieces fused with the column pass
+// that used to follow it.  Lengths 2^2 .. 2^12 (rank count x inner column length).
+template <int LOGL, int MODE, int ARITH = ARITH_MONT> using ColTile2L = ColTile<LOGL, MODE, ARITH, true>;
+template <int LOGL, int MODE, int ARITH = ARITH_MONT> using ColTileSlim2L = ColTileSlim<LOGL, MODE, ARITH, true>;
 
 // Fine tiles for transforms too small to fill the chip with 2^12-element tiles
 // (n * batch <= 2^20, or 2^21 for single-pass rows; e.g. the reference's README shape 2^17 = 2^8 x 2^9): E = 4
@@ -105,6 +111,7 @@ using ColTileFine = TileNTT<LOGL + fine_col_f0(LOGL), fine_col_f0(LOGL), LOGL, F
 template <class Status, class Stream> struct KernelEntryT {
   int kind, logl, dir, flag;
   int logt, f0, threads, loge;
+  int two_level;  // TileNTT::TWOLVL
   Status (*launch)(const PassArgs &, u32 grid, Stream);
   bool (*set_mapping_ok)();  // TileNTT::verify_set_mapping (host-side check, test tier)
   int group_barriers;        // workgroup barriers per tile (the other exchanges are wave-local)
@@ -128,6 +135,7 @@ Entry make_entry(int kind, int dir, int flag) {
   e.f0 = TN::F0;
   e.threads = TN::NT;
   e.loge = TN::LOGE;
+  e.two_level = TN::TWOLVL ? 1 : 0;
   e.launch = &Launcher<TN>::launch;
 #if !defined(__HIP_DEVICE_COMPILE__)
   e.set_mapping_ok = &TN::template verify_set_mapping<0>;
@@ -160,8 +168,20 @@ Entry make_entry(int kind, int dir, int flag) {
   make_entry<ColTileFine<L, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1), \
   make_entry<ColTileFine<L, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
 
+// entries parameterised by the arithmetic back end `ARITH` of the enclosing function
+#define SVENTT_A_ROW(L)                                                                   \
+  make_entry<RowTile<L, MODE_FWD, false, ARITH>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0), \
+  make_entry<RowTile<L, MODE_FWD, true, ARITH>, Entry, Launcher>(KIND_ROW, MODE_FWD, 1),  \
+  make_entry<RowTile<L, MODE_INV, false, ARITH>, Entry, Launcher>(KIND_ROW, MODE_INV, 0), \
+  make_entry<RowTile<L, MODE_INV, true, ARITH>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
+#define SVENTT_A_COL(T, L)                                                         \
+  make_entry<T<L, MODE_FWD, ARITH>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),        \
+  make_entry<T<L, MODE_INV, ARITH>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
+
 template <class Entry, template <class> class Launcher>
-const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int f0, int loge) {
+const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int f0, int loge,
+                                     int two_level = 0) {
+  constexpr int ARITH = ARITH_MONT;  // (SVENTT_A_COL names it)
   static const Entry table[] = {
       SVENTT_NARROW_ENTRIES(1), SVENTT_NARROW_ENTRIES(2), SVENTT_NARROW_ENTRIES(3),
       SVENTT_NARROW_ENTRIES(4), SVENTT_NARROW_ENTRIES(5), SVENTT_NARROW_ENTRIES(6),
@@ -181,6 +201,11 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
       make_entry<ColTileSlim<11, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
       make_entry<ColTileSlim<12, MODE_FWD>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),
       make_entry<ColTileSlim<12, MODE_INV>, Entry, Launcher>(KIND_COL, MODE_INV, 1),
+      SVENTT_A_COL(ColTile2L, 2), SVENTT_A_COL(ColTile2L, 3), SVENTT_A_COL(ColTile2L, 4),
+      SVENTT_A_COL(ColTile2L, 5), SVENTT_A_COL(ColTile2L, 6), SVENTT_A_COL(ColTile2L, 7),
+      SVENTT_A_COL(ColTile2L, 8), SVENTT_A_COL(ColTile2L, 9), SVENTT_A_COL(ColTile2L, 10),
+      SVENTT_A_COL(ColTile2L, 11),
+      SVENTT_A_COL(ColTileSlim2L, 10), SVENTT_A_COL(ColTileSlim2L, 11), SVENTT_A_COL(ColTileSlim2L, 12),
       SVENTT_FINE_ROW_ENTRIES(1), SVENTT_FINE_ROW_ENTRIES(2), SVENTT_FINE_ROW_ENTRIES(3),
       SVENTT_FINE_ROW_ENTRIES(4), SVENTT_FINE_ROW_ENTRIES(5), SVENTT_FINE_ROW_ENTRIES(6),
       SVENTT_FINE_ROW_ENTRIES(7), SVENTT_FINE_ROW_ENTRIES(8), SVENTT_FINE_ROW_ENTRIES(9),
@@ -192,24 +217,16 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
   };
   for (const Entry &e : table)
     if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0 &&
-        e.loge == loge)
+        e.loge == loge && e.two_level == two_level)
       return &e;
   return nullptr;
 }
 
 // The E = 16 tiles of one of the other arithmetic back ends (field64.h: ARITH_GOLD,
 // ARITH_SHOUP); plans of those back ends never use the fine tiles.  Same shapes, same lookup.
-#define SVENTT_A_ROW(L)                                                                   \
-  make_entry<RowTile<L, MODE_FWD, false, ARITH>, Entry, Launcher>(KIND_ROW, MODE_FWD, 0), \
-  make_entry<RowTile<L, MODE_FWD, true, ARITH>, Entry, Launcher>(KIND_ROW, MODE_FWD, 1),  \
-  make_entry<RowTile<L, MODE_INV, false, ARITH>, Entry, Launcher>(KIND_ROW, MODE_INV, 0), \
-  make_entry<RowTile<L, MODE_INV, true, ARITH>, Entry, Launcher>(KIND_ROW, MODE_INV, 1)
-#define SVENTT_A_COL(T, L)                                                         \
-  make_entry<T<L, MODE_FWD, ARITH>, Entry, Launcher>(KIND_COL, MODE_FWD, 1),        \
-  make_entry<T<L, MODE_INV, ARITH>, Entry, Launcher>(KIND_COL, MODE_INV, 1)
-
 template <int ARITH, class Entry, template <class> class Launcher>
-const Entry *find_arith_kernel_in_registry(int kind, int logl, int dir, int flag, int f0, int loge) {
+const Entry *find_arith_kernel_in_registry(int kind, int logl, int dir, int flag, int f0, int loge,
+                                           int two_level = 0) {
   static const Entry table[] = {
       SVENTT_A_COL(ColTileNarrow, 1), SVENTT_A_COL(ColTileNarrow, 2), SVENTT_A_COL(ColTileNarrow, 3),
       SVENTT_A_COL(ColTileNarrow, 4), SVENTT_A_COL(ColTileNarrow, 5), SVENTT_A_COL(ColTileNarrow, 6),
@@ -222,10 +239,15 @@ const Entry *find_arith_kernel_in_registry(int kind, int logl, int dir, int flag
       SVENTT_A_COL(ColTile, 7), SVENTT_A_COL(ColTile, 8), SVENTT_A_COL(ColTile, 9),
       SVENTT_A_COL(ColTile, 10), SVENTT_A_COL(ColTile, 11),
       SVENTT_A_COL(ColTileSlim, 10), SVENTT_A_COL(ColTileSlim, 11), SVENTT_A_COL(ColTileSlim, 12),
+      SVENTT_A_COL(ColTile2L, 2), SVENTT_A_COL(ColTile2L, 3), SVENTT_A_COL(ColTile2L, 4),
+      SVENTT_A_COL(ColTile2L, 5), SVENTT_A_COL(ColTile2L, 6), SVENTT_A_COL(ColTile2L, 7),
+      SVENTT_A_COL(ColTile2L, 8), SVENTT_A_COL(ColTile2L, 9), SVENTT_A_COL(ColTile2L, 10),
+      SVENTT_A_COL(ColTile2L, 11),
+      SVENTT_A_COL(ColTileSlim2L, 10), SVENTT_A_COL(ColTileSlim2L, 11), SVENTT_A_COL(ColTileSlim2L, 12),
   };
   for (const Entry &e : table)
     if (e.kind == kind && e.logl == logl && e.dir == dir && e.flag == flag && e.f0 == f0 &&
-        e.loge == loge)
+        e.loge == loge && e.two_level == two_level)
       return &e;
   return nullptr;
 }
@@ -239,6 +261,11 @@ inline int registry_col_f0(int logl, int logs, bool slim = false) {
   if (logs >= col_f0(logl)) return col_f0(logl);
   if (logs >= NARROW_F0 && logl <= 8) return NARROW_F0;
   return -1;
+}
+// is there a two-level variant (ColTile2L / ColTileSlim2L) of the column tile (logl, f0)?
+inline bool registry_has_two_level(int logl, int f0) {
+  if (logl >= 10 && logl <= 12 && f0 == SLIM_F0) return true;
+  return logl >= 2 && logl <= 11 && f0 == col_f0(logl);
 }
 inline int registry_row_logt(int logl) { return row_logt(logl); }
 inline int registry_fine_col_f0(int logl, int logs) {

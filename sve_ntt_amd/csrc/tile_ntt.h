@@ -74,13 +74,24 @@ struct PassArgs {
   u64 ostride;
   u64 src_istride;
   u64 src_ostride;
+  // TWO-LEVEL tiles only (TileNTT's TWOLVL; the row transform of the sharded six-step, whose
+  // first pass reads rows that lie in `nranks` received pieces): row i of a block is at
+  // (i >> row_split) * istride_hi + (i mod 2^row_split) * istride.  A side that is an ordinary
+  // matrix has istride_hi = istride << row_split.
+  u64 istride_hi;
+  u64 src_istride_hi;
+  u32 row_split;
   u32 tiles_per_outer;  // column tiles per block covered by THIS launch
-  // A launch may cover only a chunk of the columns (the sharded transform pipelines
-  // its all-to-all chunk by chunk): tile ct of the launch is column tile ct_first + ct,
-  // and a side whose buffer holds just the chunk rebases its column index by *_col_bias.
+  // A launch may cover only a chunk of the columns (the sharded transform pipelines its
+  // all-to-all chunk by chunk).  The chunk is 2^k equal RUNS of adjacent column tiles, one
+  // run every run_period columns (one run, run_shift = 31, unless the pass that consumes the
+  // exchanged chunk is a two-level one): tile ct of the launch is tile (ct mod 2^run_shift) of
+  // run (ct >> run_shift) and starts at column run * run_period + (ct_first + ct mod 2^run_shift) * T.
+  // A side whose buffer holds just the chunk (`compact`) numbers its columns ct * T.
   u32 ct_first;
-  u32 dst_col_bias;
-  u32 src_col_bias;
+  u32 run_shift;
+  u32 run_period;
+  u32 compact;          // bit 0: dst is compact, bit 1: src is compact
   u32 grid;             // workgroups in this launch
   // twist of the pass (six-step twiddle, layer/sve/generic.hpp:95-105,169-188):
   // omega_M^e = twist_hi[e >> twist_shift] * twist_lo[e & mask], Montgomery form
@@ -126,11 +137,14 @@ F64_HD u32 bitrev32(u32 x) {
 // ARITH: the arithmetic back end of the butterflies and of the twist (field64.h); the fold of
 // 1/L and the fused product always use the Montgomery product (their operands arrive in
 // Montgomery form whatever the back end).
+// TWOLVL: COL tiles whose rows lie at a two-level stride on one side (PassArgs::row_split): the
+// first pass of the sharded row transform, fused with the gather of the received pieces.
 template <int LOGT_, int F0_, int LOGL_, int LOGE_, int MODE_, bool FLAG_, class STEPS_,
-          int ARITH_ = ARITH_MONT>
+          int ARITH_ = ARITH_MONT, bool TWOLVL_ = false>
 struct TileNTT {
   static constexpr int LOGT = LOGT_, F0 = F0_, LOGL = LOGL_, LOGE = LOGE_, MODE = MODE_;
   static constexpr int ARITH = ARITH_;
+  static constexpr bool TWOLVL = TWOLVL_;
   static constexpr int TWW = Arith<ARITH_>::TW_WORDS;  // 64-bit words per table entry
   static constexpr bool FLAG = FLAG_;
   using STEPS = STEPS_;
@@ -142,6 +156,7 @@ struct TileNTT {
   static_assert(STEPS::sum(NSTEPS) == LOGL, "steps must cover every stage once");
   static_assert(LOGT >= LOGE && F0 + LOGL <= LOGT, "tile too small");
   static_assert(!COL || F0 + LOGL == LOGT, "a COL tile holds whole columns");
+  static_assert(COL || !TWOLVL, "only COL tiles have row strides");
 
   // ---- stage twiddles of the lower steps live in LDS ----------------------------------------
   // The vector L1 returns data in order: a twiddle load that hits in L2 still waits behind the
@@ -262,9 +277,10 @@ struct TileNTT {
       // instead of being fetched by two.  Placement affects speed only.
       if ((a.grid & 7u) == 0) block = (block & 7u) * (a.grid >> 3) + (block >> 3);
       const u32 o = block / a.tiles_per_outer, ct = block - o * a.tiles_per_outer;
-      t.c0 = (a.ct_first + ct) * (u32)T;
-      t.base = (u64)o * a.ostride + (t.c0 - a.dst_col_bias);
-      t.sbase = (u64)o * a.src_ostride + (t.c0 - a.src_col_bias);
+      const u32 run = ct >> a.run_shift, within = ct - (run << a.run_shift);
+      t.c0 = run * a.run_period + (a.ct_first + within) * (u32)T;
+      t.base = (u64)o * a.ostride + ((a.compact & 1u) ? ct * (u32)T : t.c0);
+      t.sbase = (u64)o * a.src_ostride + ((a.compact & 2u) ? ct * (u32)T : t.c0);
       t.live = true;
     } else {
       t.c0 = 0;
@@ -275,18 +291,48 @@ struct TileNTT {
     return t;
   }
 
+  // element offset of the row bits `rows` (any subset of a row index's bits: the map is additive
+  // over disjoint bit sets) on the destination / source side
+  F64_HD static u64 row_offset(const PassArgs &a, u32 rows) {
+    if constexpr (TWOLVL)
+      return (u64)(rows >> a.row_split) * a.istride_hi + (u64)(rows & ((1u << a.row_split) - 1u)) * a.istride;
+    else
+      return (u64)rows * a.istride;
+  }
+  F64_HD static u64 src_row_offset(const PassArgs &a, u32 rows) {
+    if constexpr (TWOLVL)
+      return (u64)(rows >> a.row_split) * a.src_istride_hi +
+             (u64)(rows & ((1u << a.row_split) - 1u)) * a.src_istride;
+    else
+      return (u64)rows * a.src_istride;
+  }
+
   F64_HD static u64 gaddr(const PassArgs &a, const Tile &t, u32 I) {
     if constexpr (COL)
-      return t.base + (u64)(I >> F0) * a.istride + (I & (u32)(T - 1));
+      return t.base + row_offset(a, I >> F0) + (I & (u32)(T - 1));
     else
       return t.base + I;
   }
 
   F64_HD static u64 saddr(const PassArgs &a, const Tile &t, u32 I) {
     if constexpr (COL)
-      return t.sbase + (u64)(I >> F0) * a.src_istride + (I & (u32)(T - 1));
+      return t.sbase + src_row_offset(a, I >> F0) + (I & (u32)(T - 1));
     else
       return t.sbase + I;
+  }
+  // offset of register v of a radix set (register bits from row bit LO up); `vstride` is the
+  // one-level form v * (stride << LO), which the ordinary tiles keep as it was
+  template <int LO> F64_HD static u64 dst_off(const PassArgs &a, int v, u64 vstride) {
+    if constexpr (TWOLVL)
+      return row_offset(a, (u32)v << LO);
+    else
+      return (u64)v * vstride;
+  }
+  template <int LO> F64_HD static u64 src_off(const PassArgs &a, int v, u64 vstride) {
+    if constexpr (TWOLVL)
+      return src_row_offset(a, (u32)v << LO);
+    else
+      return (u64)v * vstride;
   }
 
   F64_HD static bool in_range(const PassArgs &a, const Tile &t, u32 I) {
@@ -382,7 +428,7 @@ struct TileNTT {
 #pragma unroll
     for (int i = FIRST; i < FIRST + COUNT; i += (pairs ? 2 : 1)) {
       const int g = i >> k, v = i & (R - 1);
-      u64 *p = a.dst + gaddr(a, t, I0[g]) + (u64)v * vstride;
+      u64 *p = a.dst + gaddr(a, t, I0[g]) + dst_off<LO>(a, v, vstride);
       asm volatile("" : "+v"(p));
 #if defined(SVENTT_STUB_HBM) || defined(SVENTT_STUB_STORES)
       if (x[i] == 0x123456789abcdefull) *p = x[i];
@@ -482,7 +528,7 @@ struct TileNTT {
       s_low[g] = s & ((1u << lo) - 1u);
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
-    constexpr int TR = 6 * ((MODE == MODE_FWD) ? SI : NSTEPS - 1 - SI);  // (trace slots of this step)
+    [[maybe_unused]] constexpr int TR = 6 * ((MODE == MODE_FWD) ? SI : NSTEPS - 1 - SI);  // (trace slots of this step)
     SVENTT_STAMP(lds, TR + 0);
     // the table prefix the middle steps read from LDS: asked for first, so that it arrives first
     // (asking for the data first instead was measured: 199.0 against 196.1 us, profiles/r02/asm_stages_ab.txt)
@@ -518,9 +564,9 @@ struct TileNTT {
 #pragma unroll
         for (int v = 0; v < R; ++v)
 #if defined(SVENTT_STUB_HBM) || defined(SVENTT_STUB_LOADS)  // analysis builds only (tools/build_variant.sh)
-          x[g * R + v] = (u64)(uintptr_t)(p0 + (u64)v * vstride) >> 1;
+          x[g * R + v] = (u64)(uintptr_t)(p0 + src_off<LO>(a, v, vstride)) >> 1;
 #else
-          x[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
+          x[g * R + v] = in_range(a, t, I0[g] | ((u32)v << lo)) ? p0[src_off<LO>(a, v, vstride)] : 0;
 #endif
       } else {
         const u32 P0 = lds_phys(I0[g]);
@@ -579,9 +625,9 @@ struct TileNTT {
 #pragma unroll
           for (int v = 0; v < R; ++v)
 #if defined(SVENTT_STUB_HBM) || defined(SVENTT_STUB_STORES)
-            if (x[g * R + v] == 0x123456789abcdefull) p0[(u64)v * vstride] = x[g * R + v];
+            if (x[g * R + v] == 0x123456789abcdefull) p0[dst_off<LO>(a, v, vstride)] = x[g * R + v];
 #else
-            if (in_range(a, t, I0[g] | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
+            if (in_range(a, t, I0[g] | ((u32)v << lo))) p0[dst_off<LO>(a, v, vstride)] = x[g * R + v];
 #endif
         }
       }
@@ -748,7 +794,7 @@ struct TileNTT {
         const u64 *p0 = a.src + saddr(a, t, I0);
 #pragma unroll
         for (int v = 0; v < R; ++v)
-          x[g * R + v] = in_range(a, t, I0 | ((u32)v << lo)) ? p0[(u64)v * vstride] : 0;
+          x[g * R + v] = in_range(a, t, I0 | ((u32)v << lo)) ? p0[src_off<LO>(a, v, vstride)] : 0;
         if constexpr (twisted && MODE == MODE_INV) {
 #pragma unroll
           for (int v = 0; v < R; ++v)
@@ -804,13 +850,13 @@ struct TileNTT {
           u64 op[R];
 #pragma unroll
           for (int v = 0; v < R; ++v)
-            op[v] = in_range(a, t, I0 | ((u32)v << lo)) ? e0[(u64)v * vstride] : 0;
+            op[v] = in_range(a, t, I0 | ((u32)v << lo)) ? e0[dst_off<LO>(a, v, vstride)] : 0;
 #pragma unroll
           for (int v = 0; v < R; ++v) x[g * R + v] = montmul(x[g * R + v], op[v], a.f);
         }
 #pragma unroll
         for (int v = 0; v < R; ++v)
-          if (in_range(a, t, I0 | ((u32)v << lo))) p0[(u64)v * vstride] = x[g * R + v];
+          if (in_range(a, t, I0 | ((u32)v << lo))) p0[dst_off<LO>(a, v, vstride)] = x[g * R + v];
       } else {
 #pragma unroll
         for (int v = 0; v < R; ++v) lds[P0 ^ lds_phys((u32)v << lo)] = x[g * R + v];

@@ -44,10 +44,12 @@ using SimEntry = KernelEntryT<int, int>;
 const SimEntry *find_sim_kernel(const HostPass &h, int flag) {
   const int dir = h.inverse ? MODE_INV : MODE_FWD;
   if (h.arith == ARITH_GOLD)
-    return find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
+    return find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge,
+                                                                            h.two_level);
   if (h.arith == ARITH_SHOUP)
-    return find_arith_kernel_in_registry<ARITH_SHOUP, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
-  return find_kernel_in_registry<SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge);
+    return find_arith_kernel_in_registry<ARITH_SHOUP, SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge,
+                                                                             h.two_level);
+  return find_kernel_in_registry<SimEntry, SimLauncher>(h.kind, h.logl, dir, flag, h.f0, h.loge, h.two_level);
 }
 
 thread_local std::string g_err;
@@ -88,23 +90,24 @@ template <class F> int check_table(F find) {
       for (int dir = 0; dir < 2; ++dir)
         for (int flag = 0; flag < 2; ++flag)
           for (int f0 = 0; f0 <= 11; ++f0)
-            for (int loge : {2, 4}) {
-              const SimEntry *e = find(kind, logl, dir, flag, f0, loge);
-              if (!e) continue;
-              ++n;
-              if (!e->set_mapping_ok()) return -n;
-            }
+            for (int loge : {2, 4})
+              for (int two = 0; two < 2; ++two) {
+                const SimEntry *e = find(kind, logl, dir, flag, f0, loge, two);
+                if (!e) continue;
+                ++n;
+                if (!e->set_mapping_ok()) return -n;
+              }
   return n;
 }
 
 extern "C" {
 
 int sim_check_set_mappings(void) {
-  const int a = check_table([](int k, int l, int d, int fl, int f0, int e) {
-    return find_kernel_in_registry<SimEntry, SimLauncher>(k, l, d, fl, f0, e); });
+  const int a = check_table([](int k, int l, int d, int fl, int f0, int e, int two) {
+    return find_kernel_in_registry<SimEntry, SimLauncher>(k, l, d, fl, f0, e, two); });
   if (a < 0) return a;
-  const int b = check_table([](int k, int l, int d, int fl, int f0, int e) {
-    return find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(k, l, d, fl, f0, e); });
+  const int b = check_table([](int k, int l, int d, int fl, int f0, int e, int two) {
+    return find_arith_kernel_in_registry<ARITH_GOLD, SimEntry, SimLauncher>(k, l, d, fl, f0, e, two); });
   if (b < 0) return b - 100000;
   return a + b;
 }
@@ -175,7 +178,8 @@ int sim_sharded_rows_pass(uint64_t p, uint64_t g, uint64_t n, uint32_t r_log2, i
   const HostPass &h = passes[(size_t)index];
   const SimEntry *e = find_sim_kernel(h, h.flag ? 1 : 0);
   if (!e) return PLAN_ERR_LOGIC;
-  if (dst == src && (h.src_istride != h.dst_istride || h.src_ostride != h.dst_ostride)) {
+  if (dst == src && (h.src_istride != h.dst_istride || h.src_ostride != h.dst_ostride ||
+                     h.src_istride_hi != h.dst_istride_hi)) {
     g_err = "gather/scatter passes cannot run in place";
     return PLAN_ERR_INVALID_ARGUMENT;
   }
@@ -214,8 +218,7 @@ int64_t sim_sharded_tiles_per_block(uint64_t p, uint64_t g, uint64_t n, uint32_t
   int rc = which == 0 ? build_sharded_plan(pl, p, g, n, r_log2, rank, nranks, PLAN_FORWARD, g_err)
                       : build_sharded_rows_plan(pl, p, g, n, r_log2, rank, nranks, PLAN_FORWARD, g_err);
   if (rc) return rc;
-  const HostPass &h = pl.fwd.front();
-  return (int64_t)(h.istride >> h.f0);
+  return (int64_t)pass_chunk_tiles(pl.fwd.front());
 }
 
 // Planner introspection: writes up to `cap` entries of (kind, logl, f0, logt, grid, loge) per pass.

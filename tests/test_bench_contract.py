@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int,
             "ms_per_step": float, "higher_is_better": bool, "scaling": str, "dtype": str, "data": str,
-            "config": dict, "roofline": dict, "cpu_baseline": dict}
+            "config": dict, "roofline": dict, "cpu_baseline": dict, "verified": bool, "verification": dict}
 
 
 @pytest.mark.gpu
@@ -50,6 +50,35 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0
+    # time-then-verify (tests/bench-ntt.cpp:37-64 of the reference): the timed loop's output was
+    # compared with the CPU leg's result on the same input, with the closed form and with the golden digest
+    assert out["verified"] is True
+    checks = " | ".join(out["verification"]["checks"])
+    assert "cpu_baseline" in checks and "closed form" in checks and "golden" in checks, checks
+    with open(os.path.join(ROOT, "tests", "golden", "ntt_digests.json")) as f:
+        gold = [c for c in json.load(f)["cases"]
+                if c["prime"] == "baseline" and c["log2m"] == 24 and c["input"]["kind"] == "iota"][0]
+    assert out["verification"]["digest"] == {"xor": gold["forward_digest"][1], "sum": gold["forward_digest"][2]}
+    assert "0x0123456789abcdef + i" in out["config"]["input"] and "start+i" in cpu["sample"]
+
+
+@pytest.mark.gpu
+def test_bench_fails_when_the_kernels_are_wrong():
+    """A library whose kernels do not store their results (-DSVENTT_STUB_STORES, an analysis build
+    of tools/build_variant.sh) times fine and must NOT yield a result line: bench.py exits non-zero."""
+    lib = os.path.join(ROOT, "sve_ntt_amd", "build", "lib_stub_stores.so")
+    main = os.path.join(ROOT, "sve_ntt_amd", "libsventt_hip.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(main):
+        b = subprocess.run([os.path.join(ROOT, "tools", "build_variant.sh"), "stub_stores", "-DSVENTT_STUB_STORES"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert b.returncode == 0, b.stderr[-2000:]
+    env = dict(os.environ, SVENTT_HIP_LIBRARY=lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                        "--prewarm", "10", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "VERIFICATION FAILED" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.gpu
@@ -63,6 +92,7 @@ def test_bench_other_configs_share_the_schema(config, elements):
     for key, typ in REQUIRED.items():
         if key != "cpu_baseline":
             assert key in out and isinstance(out[key], typ), key
+    assert out["verified"] is True and out["verification"]["digest"]
     assert out["config"]["name"] == config and out["config"]["elements_per_step"] == elements
     per_step = elements * (2 if config == "roundtrip" else 1)
     assert abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6

@@ -119,6 +119,82 @@ def test_random_sharded_shapes_in_process():
     assert done >= 25, done
 
 
-@pytest.mark.parametrize("world,log2n,r_log2,chunks", [(8, 20, 11, 4), (2, 14, 1, 2), (4, 12, 2, 1)])
+@pytest.mark.parametrize("world,log2n,r_log2,chunks", [(8, 20, 11, 4), (2, 14, 1, 2), (4, 12, 2, 1),
+                                                        (2, 20, 12, 2)])  # R = 2^12: the slim tiles' longest column
 def test_edge_sharded_shapes_in_process(world, log2n, r_log2, chunks):
     run_case(world, log2n, r_log2, chunks, seed=99)
+
+
+@pytest.mark.parametrize("world,log2n,r_log2,chunks", [
+    (8, 22, 3, 4),   # rows of C = 2^19 on 8 ranks: col 2^6 (two-level) | row 2^13 -- BASELINE config #5's row phase
+    (4, 21, 4, 2),   # C = 2^17 on 4 ranks: col 2^4 (two-level, 4 rows per piece) | row 2^13
+    (2, 18, 3, 4),   # C = 2^15 on 2 ranks: col 2^3 (two-level) | row 2^12
+    (8, 22, 3, 1)])  # the same as the first without pipelining
+def test_fused_gather_shapes_in_process(world, log2n, r_log2, chunks):
+    """The first pass of the row phase is longer than the rank count: it reads `rows per piece`
+    rows from each received piece (two-level strides) and the column phase cuts its exchange
+    chunks run by run (plan_core.h: sharded_row_split, make_chunk_args)."""
+    from tests import simlib
+    L = simlib.load()
+    args = (P, G, 1 << log2n, r_log2, 0, world)
+    assert L.sim_sharded_rows_num_passes(*args) == 2
+    used = run_case(world, log2n, r_log2, chunks, seed=7)
+    assert used == chunks
+
+
+def test_config5_row_phase_is_two_sweeps():
+    """N = 2^30 on 8 ranks, R = 2^11 (BASELINE configs[4]): one column sweep, the exchange, then
+    col 2^6 | row 2^13 -- three sweeps of the rank's 1 GiB, not four."""
+    from tests import simlib
+    L = simlib.load()
+    for rank in (0, 7):
+        assert L.sim_sharded_rows_num_passes(P, G, 1 << 30, 11, rank, 8) == 2
+    assert L.sim_sharded_rows_num_passes(P, G, 1 << 30, 12, 0, 8) == 2      # R = 2^12 is allowed now
+    assert L.sim_sharded_rows_num_passes(P, G, 1 << 27, 11, 0, 8) == 2      # 2^24 per rank: col 2^3 | row 2^13
+    # the column phase cuts its chunks per run of 2^13 columns: 2^11 tiles of 4 columns per run
+    assert L.sim_sharded_tiles_per_block(P, G, 1 << 30, 11, 0, 8, 0) == 2048
+    assert L.sim_sharded_tiles_per_block(P, G, 1 << 30, 11, 0, 8, 1) == 128  # col 2^6 x T64 over 2^13 columns
+
+
+@pytest.mark.parametrize("log2n,r_log2,chunks", [(18, 4, 4), (18, 2, 1), (20, 5, 2)])
+def test_one_rank_sharded_pipeline_on_the_host_replay(log2n, r_log2, chunks):
+    """A single rank runs the same pipeline (tests/cpp/rccl_one_rank.cpp executes it over a one-rank
+    RCCL communicator on the GPU): column pass chunk -> exchange with itself -> first row-phase pass
+    on the chunk -> remaining row passes; inverse mirrored."""
+    from tests import simlib
+    L = simlib.load()
+    port = oracle.port()
+    n = 1 << log2n
+    args = (P, G, n, r_log2, 0, 1)
+    full = port.fill_splitmix(n, 31, P)
+    want = port.forward(full, P, G)
+    npass = L.sim_sharded_rows_num_passes(*args)
+    assert npass >= 2
+    for which in (0, 1):
+        assert L.sim_sharded_tiles_per_block(*args, which) % chunks == 0
+    piece = n // chunks
+    work = np.zeros(n, dtype=np.uint64)
+    dst = np.full(n, 0x5555555555555555, dtype=np.uint64)
+    for k in range(chunks):
+        wk = work[k * piece:(k + 1) * piece]
+        assert L.sim_sharded_chunk(*args, 0, 0, k, chunks, 1, 0, simlib._ptr(wk), simlib._ptr(full)) == 0
+    recv = work.copy()  # the exchange of one rank with itself
+    for k in range(chunks):
+        rk = recv[k * piece:(k + 1) * piece]
+        assert L.sim_sharded_chunk(*args, 1, 0, k, chunks, 0, 1, simlib._ptr(dst), simlib._ptr(rk)) == 0
+    for i in range(1, npass):
+        assert L.sim_sharded_rows_pass(*args, 0, i, simlib._ptr(dst), simlib._ptr(dst)) == 0
+    assert np.array_equal(dst, want)
+    # inverse: row passes but the last, the last one scatters per chunk, exchange, column pass per chunk
+    cur = dst.copy()
+    for i in range(npass - 1):
+        assert L.sim_sharded_rows_pass(*args, 1, i, simlib._ptr(cur), simlib._ptr(cur)) == 0
+    for k in range(chunks):
+        wk = work[k * piece:(k + 1) * piece]
+        assert L.sim_sharded_chunk(*args, 1, 1, k, chunks, 1, 0, simlib._ptr(wk), simlib._ptr(cur)) == 0
+    recv = work.copy()
+    back = np.full(n, 0x5555555555555555, dtype=np.uint64)
+    for k in range(chunks):
+        rk = recv[k * piece:(k + 1) * piece]
+        assert L.sim_sharded_chunk(*args, 0, 1, k, chunks, 0, 1, simlib._ptr(back), simlib._ptr(rk)) == 0
+    assert np.array_equal(back, full)
