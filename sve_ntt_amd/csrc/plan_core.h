@@ -263,17 +263,54 @@ inline int make_host_pass(const HostPlan &pl, HostPass &ps, int kind, int logl, 
   return PLAN_OK;
 }
 
+// Measured time of one pass over data that does not fit the Infinity Cache, in us per 2^24 elements
+// on MI355X (tools/split3_search.py, profiles/r03/split3_search.txt: 2^28..2^31 points, every
+// admissible three-pass split).  where = 0: the first column pass (rows tens of MiB apart: what
+// counts is the width of the tile, T >= 32 columns = 256-byte segments up to 2^7; a 2^9 x T8 pass
+// touches 512 different pages with 64 bytes each and takes 140 us), 1: a later column pass (rows
+// 32-64 KiB apart; cheap up to 2^8, the 32-byte segments of the slim 2^10..2^12 tiles cost 40 % more),
+// 2: the row pass.  r02 split the column stages evenly (2^30 as 9 | 8 | 13: 317 us per 2^24; now
+// 7 | 11 | 12: 289).
+inline int large_pass_cost(int where, int logl) {
+  static const int first[13] = {0, 51, 56, 61, 73, 99, 92, 89, 105, 139, 180, 180, 180};
+  static const int later[13] = {0, 66, 68, 70, 72, 74, 76, 78, 82, 98, 124, 118, 133};
+  if (where == 2) return logl >= 13 ? 92 : 80;
+  return (where == 0 ? first : later)[logl < 1 ? 1 : (logl > 12 ? 12 : logl)];
+}
+
 // Split log2(n) into pass lengths: every COL pass <= MAX_COL_LOGL, the final ROW
 // pass <= MAX_ROW_LOGL.  n0_log2 (if non-zero) fixes the first COL pass (the R
 // of the reference's n = R x C six-step, kernel/recursive.hpp:61-75).
+// `large`: the whole array (n * batch) does not fit the Infinity Cache (>= 2^26 elements).
 inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row, std::string &err,
-                        bool fine = false) {
+                        bool fine = false, bool large = false) {
   cols.clear();
   if (fine) {  // at most two passes; the caller checked that the fine tiles cover the shape
     const int c = n0_log2 ? (int)n0_log2 : (logn <= MAX_FINE_ROW_LOGL ? 0 : logn / 2);
     if (c) cols.push_back(c);
     row = logn - c;
     return PLAN_OK;
+  }
+  // SVENTT_SPLIT="c0,c1,...,row" (log2 of every pass length; developer knob, tools/split3_search.py):
+  // used when it fits this transform, ignored otherwise
+  if (const char *e = std::getenv("SVENTT_SPLIT"); e && n0_log2 == 0) {
+    std::vector<int> v;
+    for (const char *q = e; *q;) {
+      v.push_back(std::atoi(q));
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+    int sum = 0;
+    bool ok = !v.empty();
+    for (size_t i = 0; i < v.size(); ++i) {
+      sum += v[i];
+      ok = ok && v[i] >= 1 && v[i] <= (i + 1 == v.size() ? MAX_ROW_LOGL : tuning().max_col_logl);
+    }
+    if (ok && sum == logn) {
+      row = v.back();
+      cols.assign(v.begin(), v.end() - 1);
+      return PLAN_OK;
+    }
   }
   int rem = logn;
   if (n0_log2 != 0) {
@@ -288,6 +325,24 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
     row = rem;
     return PLAN_OK;
   }
+  // Three passes (2^26 points and more: the data no longer fits the 256 MiB Infinity Cache and every
+  // pass is a sweep of HBM): the split with the smallest modelled time.
+  if (n0_log2 == 0 && rem > MAX_ROW_LOGL + tuning().max_col_logl) {
+    int best = 1 << 30, ba = 0, bb = 0, br = 0;
+    for (int r = MAX_ROW_LOGL - 1; r <= MAX_ROW_LOGL; ++r)
+      for (int a = 1; a <= tuning().max_col_logl; ++a) {
+        const int b = rem - r - a;
+        if (b < 1 || b > tuning().max_col_logl) continue;
+        const int c = large_pass_cost(0, a) + large_pass_cost(1, b) + large_pass_cost(2, r);
+        if (c < best) best = c, ba = a, bb = b, br = r;
+      }
+    if (ba) {
+      cols.push_back(ba);
+      cols.push_back(bb);
+      row = br;
+      return PLAN_OK;
+    }
+  }
   // Widest smallest tile of the column pass is 2^3 columns: the row pass (the
   // block of contiguous elements below the innermost column pass) is >= 2^3.
   // The longest row pass wins (fully contiguous 512-byte wave accesses, the column pass keeps
@@ -295,6 +350,12 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
   // of 2^14..2^21-point transforms (2^24 elements in all) are 3-12 % faster than with a balanced
   // split (tools/split_search.py, r01).  Columns shorter than 2^3 are not worth a 2^13 row.
   row = (rem - MAX_ROW_LOGL >= 3) ? MAX_ROW_LOGL : MAX_ROW_LOGL - 1;
+  // out of the cache a 2^12 row pass is 12 us per 2^24 elements cheaper than a 2^13 one and a column
+  // pass of up to 2^8 costs 2-4 us per extra stage (large_pass_cost): rows of 2^19 run as 7 | 12
+  if (large && n0_log2 == 0 && rem > MAX_ROW_LOGL && rem - (MAX_ROW_LOGL - 1) <= tuning().max_col_logl &&
+      large_pass_cost(1, rem - (MAX_ROW_LOGL - 1)) + large_pass_cost(2, MAX_ROW_LOGL - 1) <
+          large_pass_cost(1, rem - MAX_ROW_LOGL) + large_pass_cost(2, MAX_ROW_LOGL))
+    row = MAX_ROW_LOGL - 1;
   if (row > rem - 1) row = rem - 1;
   rem -= row;
   // (2^25 = 2^12 x 2^13 in two passes beats three: 581 vs 624 us forward, r01)
@@ -421,7 +482,7 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
     pl.fine = (int)n0_log2 < logn && (int)n0_log2 <= MAX_FINE_COL_LOGL &&
               logn - (int)n0_log2 <= MAX_FINE_ROW_LOGL &&
               registry_fine_col_f0((int)n0_log2, logn - (int)n0_log2) >= 0;
-  if ((rc = choose_split(logn, n0_log2, cols, row, err, pl.fine))) return rc;
+  if ((rc = choose_split(logn, n0_log2, cols, row, err, pl.fine, pl.total >= (1ull << 26)))) return rc;
   const u64 divisor = inverse_divisor ? inverse_divisor % p : n % p;
   if (divisor == 0) {
     err = "inverse divisor is a multiple of the modulus";
@@ -479,8 +540,8 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
 // A single rank (logg = 0; the whole pipeline on one GPU, exchange with itself) has one piece, which
 // IS the row: its first pass is two-level only to run the same code as the multi-rank plans.
 inline int sharded_row_split(int logc, int logg, std::vector<int> &cols, int &row, bool &two_level,
-                             std::string &err) {
-  int rc = choose_split(logc, 0, cols, row, err);
+                             std::string &err, bool large = false) {
+  int rc = choose_split(logc, 0, cols, row, err, false, large);
   if (rc) return rc;
   two_level = false;
   bool ok = tuning().sharded_fuse && !cols.empty() && cols[0] >= logg;
@@ -488,7 +549,7 @@ inline int sharded_row_split(int logc, int logg, std::vector<int> &cols, int &ro
     const int f0 = registry_col_f0(cols[0], logc - cols[0], tuning().col_slim);
     ok = two_level = f0 >= 0 && registry_has_two_level(cols[0], f0);
   }
-  if (!ok && logg > 0) rc = choose_split(logc, (u32)logg, cols, row, err);  // a gather pass of its own, then the rest
+  if (!ok && logg > 0) rc = choose_split(logc, (u32)logg, cols, row, err, false, large);  // a gather pass of its own, then the rest
   if (!rc && cols.empty()) {
     err = "rows too short for a column pass next to the exchange";  // (one rank, C <= 2^13)
     rc = PLAN_ERR_INVALID_ARGUMENT;
@@ -535,7 +596,8 @@ inline int build_sharded_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2, int
     int row = 0;
     bool two_level = false;
     std::string ignored;
-    if (sharded_row_split(logc, logg, cols, row, two_level, ignored) == PLAN_OK && cols[0] > logg)
+    if (sharded_row_split(logc, logg, cols, row, two_level, ignored, pl.total >= (1ull << 26)) == PLAN_OK &&
+        cols[0] > logg)
       chunk_period = C >> cols[0];
   }
   if (flags & PLAN_FORWARD) {
@@ -594,7 +656,7 @@ inline int build_sharded_rows_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 r_log2
   std::vector<int> cols;
   int row = 0;
   bool two_level = false;
-  if ((rc = sharded_row_split(logc, logg, cols, row, two_level, err))) return rc;
+  if ((rc = sharded_row_split(logc, logg, cols, row, two_level, err, pl.total >= (1ull << 26)))) return rc;
   // the pass next to the exchange: row i = s * Lc + i' of a block is row i' of piece s
   const int lc_log = cols[0] - logg;
   auto piece_side = [&](HostPass &ps, u64 &istride, u64 &istride_hi, u64 &ostride, u64 &other_hi) {

@@ -151,9 +151,9 @@ def test_config5_row_phase_is_two_sweeps():
         assert L.sim_sharded_rows_num_passes(P, G, 1 << 30, 11, rank, 8) == 2
     assert L.sim_sharded_rows_num_passes(P, G, 1 << 30, 12, 0, 8) == 2      # R = 2^12 is allowed now
     assert L.sim_sharded_rows_num_passes(P, G, 1 << 27, 11, 0, 8) == 2      # 2^24 per rank: col 2^3 | row 2^13
-    # the column phase cuts its chunks per run of 2^13 columns: 2^11 tiles of 4 columns per run
-    assert L.sim_sharded_tiles_per_block(P, G, 1 << 30, 11, 0, 8, 0) == 2048
-    assert L.sim_sharded_tiles_per_block(P, G, 1 << 30, 11, 0, 8, 1) == 128  # col 2^6 x T64 over 2^13 columns
+    # rows of 2^19 run as col 2^7 | row 2^12 out of the cache: the column phase cuts its chunks per run of 2^12 columns
+    assert L.sim_sharded_tiles_per_block(P, G, 1 << 30, 11, 0, 8, 0) == 1024
+    assert L.sim_sharded_tiles_per_block(P, G, 1 << 30, 11, 0, 8, 1) == 128  # col 2^7 x T32 over 2^12 columns
 
 
 @pytest.mark.parametrize("log2n,r_log2,chunks", [(18, 4, 4), (18, 2, 1), (20, 5, 2)])

@@ -2,7 +2,7 @@
 """Times the LOCAL phases one rank runs in the sharded six-step (no communication),
 for world sizes 2, 4, 8 at 2^L elements per rank (default L = 24; 27 = the per-rank size of
 BASELINE configs[4], which bench.py --gpus G runs) -- what a rank does between the exchanges.
-Run on a one-GPU box:  python tools/bench_sharded_local.py [L] [worlds, e.g. 8 or 2,4,8]
+Run on a one-GPU box:  python tools/bench_sharded_local.py [L] [worlds, e.g. 8 or 2,4,8] [log2 R, default 11]
 SVENTT_SHARDED_FUSE=0 gives r02's plans (a gather pass of its own) for a before/after."""
 import os
 import sys
@@ -17,6 +17,7 @@ from sve_ntt_amd.sharded import HipShardEngine  # noqa: E402
 
 LOG2_LOCAL = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 WORLDS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (2, 4, 8)
+R_LOG2 = int(sys.argv[3]) if len(sys.argv) > 3 else 11  # rows of the six-step (the length of the column phase)
 n_local = 1 << LOG2_LOCAL
 rng = np.random.default_rng(0)
 src = torch.from_numpy(rng.integers(0, eng.BASELINE_MODULUS.modulus, size=n_local, dtype=np.uint64)
@@ -26,7 +27,7 @@ recv = torch.empty_like(src)
 out = torch.empty_like(src)
 iters = 30
 for world in WORLDS:
-    e = HipShardEngine(eng.BASELINE_MODULUS, n_local * world, 11, 0, world)
+    e = HipShardEngine(eng.BASELINE_MODULUS, n_local * world, R_LOG2, 0, world)
     names = e.describe().split(" | ")
 
     def run(ev=None):
