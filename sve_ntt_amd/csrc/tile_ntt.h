@@ -45,6 +45,16 @@ enum : int { MODE_FWD = 0, MODE_INV = 1 };
 #ifndef SVENTT_EARLY_STORES
 #define SVENTT_EARLY_STORES 1  // 0: A/B builds that store a thread's 16 outputs together at the end
 #endif
+// Wave priority (s_setprio, 0..3) while a tile's first step issues its HBM loads / its last step its
+// stores.  VALU issue goes to the highest priority, then to the oldest wave: a workgroup that has just
+// started is the youngest on its SIMDs and computes its load addresses in whatever slots the
+// other workgroup's butterflies leave (A/B: profiles/r03/asm_stages_ab.txt).
+#ifndef SVENTT_PRIO_LOAD
+#define SVENTT_PRIO_LOAD 0
+#endif
+#ifndef SVENTT_PRIO_STORE
+#define SVENTT_PRIO_STORE 0
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SVENTT_NO_STAGE_ASM)
 #define SVENTT_STAGE_ASM 1
 #include "stage_asm.inc"
@@ -529,6 +539,7 @@ struct TileNTT {
       I0[g] = ((s >> lo) << hi) | s_low[g];
     }
     [[maybe_unused]] constexpr int TR = 6 * ((MODE == MODE_FWD) ? SI : NSTEPS - 1 - SI);  // (trace slots of this step)
+    if constexpr (from_hbm && SVENTT_PRIO_LOAD > 0) __builtin_amdgcn_s_setprio(SVENTT_PRIO_LOAD);
     SVENTT_STAMP(lds, TR + 0);
     // the table prefix the middle steps read from LDS: asked for first, so that it arrives first
     // (asking for the data first instead was measured: 199.0 against 196.1 us, profiles/r02/asm_stages_ab.txt)
@@ -575,6 +586,7 @@ struct TileNTT {
       }
     }
     SVENTT_STAMP(lds, TR + 2);
+    if constexpr (from_hbm && SVENTT_PRIO_LOAD > 0) __builtin_amdgcn_s_setprio(0);
     if constexpr (tw_fill) {
       // (the data loads above are in flight; every wave is waiting for them anyway)
 #pragma unroll
@@ -608,6 +620,7 @@ struct TileNTT {
     // ---- scatter -------------------------------------------------------------
     if constexpr (to_hbm) {
       if constexpr (twist_out) twist_all<k, LO>(a, t, x, I0, f0, zr, c);
+      if constexpr (SVENTT_PRIO_STORE > 0) __builtin_amdgcn_s_setprio(SVENTT_PRIO_STORE);
       if constexpr (multiply_out) {
         const Operands o1 = epilogue_load<k, LO, 1>(a, t, I0);
         MontGroup<0>::run(x, o0.v[0], o0.v[1], o0.v[2], o0.v[3], zr, c);

@@ -82,10 +82,58 @@ def mont_core_chain(S, dl, dh):
                   ['v_mul_hi_u32 v%d, v%d, %%[n0]' % (z, m1)]))
 
 
+def mont_core_prime(S, dl, dh):
+    """VERDICT r02 item 5 (r01 item 1b): hi64(q*N) from the shape of the BASELINE prime instead of a
+    64 x 64 product.  N = 2^64 - k*2^31 + 1 (k = 1827), so q*N = q*2^64 - (E << 31) + q with E = q*k
+    (75 bits: two v_mad_u64_u32 instead of v_mul_hi + three v_mad), and with
+    A = E >> 33, B = (E << 31) mod 2^64:   hi64(q*N) = q - A - [B > q].
+    Costs two multiplier instructions less and four shift/compare/subtract instructions more than the
+    generic chain (9 + 1 v_mov against 5 + 1 v_mov).  q itself stays generic: from the shape of
+    N^-1 = 1 + k*2^31 + 2^62 it would be one multiplier instruction + 4 slow + 5 fast against
+    3 multiplier + 1 slow (gen_stage_asm.py: mont)."""
+    m0, m1, m2, h, z, d = S.m0, S.m1, S.m2, S.h, S.z, S.d
+
+    def chain(x0, x1, y0, y1, mid, top, first):
+        return first + [
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(mid), x0, y1, pair(z)),
+            'v_mad_u64_u32 %s, %s, %s, %s, %s' % (pair(mid), S.sc, x1, y0, pair(mid)),
+            'v_mov_b32 v%d, v%d' % (z, mid + 1),
+            'v_mad_u64_u32 %s, vcc, %s, %s, %s' % (pair(top), x1, y1, pair(z)),
+            'NOPGAP',
+            'v_addc_co_u32 v%d, vcc, 0, v%d, %s' % (top + 1, top + 1, S.sc),
+        ]
+    return (chain('v%d' % dl, 'v%d' % dh, S.w0, S.w1, m2, h,
+                  ['v_mad_u64_u32 %s, vcc, v%d, %s, 0' % (pair(m0), dl, S.w0),
+                   'v_mov_b32 v%d, v%d' % (z, m0 + 1)]) +
+            ['v_mad_u64_u32 %s, vcc, v%d, %%[ni0], 0' % (pair(m1), m0),
+             'v_mul_lo_u32 v%d, v%d, %%[ni1]' % (m0 + 1, m0),
+             'v_mul_lo_u32 v%d, v%d, %%[ni0]' % (m2, m2),
+             'v_add3_u32 v%d, v%d, v%d, v%d' % (m1 + 1, m1 + 1, m0 + 1, m2),
+             # E = q * k: (e0, e1, e2) = (m0, m2, m2+1)
+             'v_mad_u64_u32 %s, vcc, v%d, %%[k], 0' % (pair(m0), m1),
+             'v_mov_b32 v%d, v%d' % (z, m0 + 1),
+             'v_mad_u64_u32 %s, vcc, v%d, %%[k], %s' % (pair(m2), m1 + 1, pair(z)),
+             # B = (E << 31) mod 2^64 -> d pair (the multiplicand is dead by now)
+             'v_lshlrev_b32 v%d, 31, v%d' % (d, m0),
+             'v_alignbit_b32 v%d, v%d, v%d, 1' % (d + 1, m2, m0),
+             # A = E >> 33 -> m0 pair
+             'v_alignbit_b32 v%d, v%d, v%d, 1' % (m0, m2 + 1, m2),
+             'v_lshrrev_b32 v%d, 1, v%d' % (m0 + 1, m2 + 1),
+             'v_cmp_gt_u64 %s, %s, %s' % (S.sb, pair(d), pair(m1)),
+             'NOPGAP',
+             'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (m2, S.sc, m1, m0, S.sb),
+             'NOPGAP',
+             'v_subb_co_u32 v%d, %s, v%d, v%d, %s' % (m2 + 1, S.sc, m1 + 1, m0 + 1, S.sc)])
+
+
 import os
 FIXMODE = os.environ.get('FIXMODE', 'exec')
-if os.environ.get('MONT', 'chain') == 'chain':  # MONT=movs: the r02a form with seven zero-extending v_mov
+MONT = os.environ.get('MONT', 'chain')
+mont_core_movs = mont_core
+if MONT == 'chain':  # MONT=movs: the r02a form with seven zero-extending v_mov
     mont_core = mont_core_chain
+if MONT == 'prime':
+    mont_core = mont_core_prime
 def fix(mask_expr, reg):
     if FIXMODE == 'none':
         return []
@@ -94,9 +142,10 @@ def fix(mask_expr, reg):
     return [mask_expr, 'v_lshl_add_u64 %s, %s, 0, %%[N]' % (pair(reg), pair(reg))]
 
 
-def bfly_fwd(S):
+def bfly_fwd(S, core=None):
     """list of items; an item is a str (one instruction) or a tuple ('fix', [instrs]) that must
     run with EXEC narrowed and is followed by a restore."""
+    core = core or mont_core
     x, y = S.xl, S.yl
     items = [
         'v_mov_b32 v%d, 0' % (S.z + 1),
@@ -109,7 +158,7 @@ def bfly_fwd(S):
         'NOPGAP',
         ('fix', fix('s_andn2_b64 exec, %%[save], %s' % S.sc, x)),
     ]
-    items += mont_core(S, S.d, S.d + 1)
+    items += core(S, S.d, S.d + 1)
     items += [
         'v_sub_co_u32 v%d, %s, v%d, v%d' % (S.yl, S.sb, S.h, S.m2),
         'NOPGAP',
@@ -152,7 +201,7 @@ def interleave(streams):
     return out
 
 
-def asm_stmt(pairs, wnames, W):
+def asm_stmt(pairs, wnames, W, core=None):
     """one asm statement for W butterflies; pairs = [(a, b)], wnames = C expressions"""
     slots = []
     ops_in = []
@@ -160,7 +209,7 @@ def asm_stmt(pairs, wnames, W):
         slots.append(Slot(s, a, b, '%%[w%d0]' % s, '%%[w%d1]' % s))
         ops_in.append('[w%d0] "v"((u32)(%s))' % (s, wn))
         ops_in.append('[w%d1] "v"((u32)((%s) >> 32))' % (s, wn))
-    body = interleave([bfly_fwd(S) for S in slots])
+    body = interleave([bfly_fwd(S, core) for S in slots])
     text = ''.join('      "%s\\n\\t"\n' % l for l in body)
     outs = []
     for (a, b) in pairs:
@@ -168,6 +217,8 @@ def asm_stmt(pairs, wnames, W):
         outs.append('"+{v[%d:%d]}"(x%d)' % (2 * b, 2 * b + 1, b))
     consts = ['[N] "s"(f.N)', '[negN] "s"(f.negN)', '[n0] "s"((u32)f.N)', '[n1] "s"((u32)(f.N >> 32))',
               '[ni0] "s"((u32)f.Ninv)', '[ni1] "s"((u32)(f.Ninv >> 32))', '[save] "s"(save)']
+    if core is mont_core_prime:
+        consts.append('[k] "s"((u32)((0ull - f.N + 1ull) >> 31))')  # N = 2^64 - k*2^31 + 1
     clob = ['"vcc"', '"scc"']
     clob += ['"v%d"' % r for r in range(TEMP_BASE, TEMP_BASE + TEMP_PER_SLOT * W)]
     clob += ['"s%d"' % r for r in range(SG_BASE, SG_BASE + 4 * W)]
@@ -175,8 +226,8 @@ def asm_stmt(pairs, wnames, W):
             % (text, ', '.join(outs), ', '.join(ops_in + consts), ', '.join(clob)))
 
 
-def kernel(W):
-    lines = ['__global__ __launch_bounds__(512) void k_asm_w%d(u64 *out, Field f, u64 seed) {' % W,
+def kernel(W, core=None, name=None):
+    lines = ['__global__ __launch_bounds__(512) void %s(u64 *out, Field f, u64 seed) {' % (name or 'k_asm_w%d' % W),
              '  u64 x[16], w[8];', '  init(x, w, f, seed);']
     lines.append('  u64 ' + ', '.join('x%d = x[%d]' % (i, i) for i in range(16)) + ';')
     lines.append('  const u64 save = __builtin_amdgcn_read_exec();')
@@ -184,7 +235,7 @@ def kernel(W):
     for r in (3, 2, 1, 0):
         bf = [(v, v + (1 << r)) for v in range(16) if not v & (1 << r)]
         for g in range(0, 8, W):
-            lines.append(asm_stmt(bf[g:g + W], ['w[%d]' % (g + k) for k in range(W)], W))
+            lines.append(asm_stmt(bf[g:g + W], ['w[%d]' % (g + k) for k in range(W)], W, core))
     lines.append('  }')
     lines.append('  u64 *o = out + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;')
     lines.append('  ' + ' '.join('o[%d] = x%d;' % (i, i) for i in range(16)))
@@ -198,6 +249,43 @@ def main():
     tail = src[src.index('template <class K> static int timeit'):src.index('int main()')]
     print('// GENERATED by tools/gen_ubench_bfly3.py -- do not edit.  W-way interleaved assembly butterflies.')
     print(head)
+    if MONT == 'both':
+        # the shipped chain against the BASELINE-prime form of hi64(q*N), 4 butterflies per statement, single
+        # launches and ~1 s of back-to-back launches (the chip at its power limit, as in the transforms)
+        print(kernel(4, mont_core_chain, 'k_asm_chain_w4'))
+        print(kernel(4, mont_core_prime, 'k_asm_prime_w4'))
+        print(tail)
+        print('''template <class K> static int sustained(const char *name, K kernel, u64 *d, int blocksPerCU, size_t lds) {
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const Field f{0xfffffc6e80000001ull, 0x4000039180000001ull, 0ull - 0xfffffc6e80000001ull};
+  const int blocks = 256 * blocksPerCU;
+  for (int i = 0; i < 3000; ++i) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, 0, d, f, 0x1234567ull);
+  CHECK(hipEventRecord(e0));
+  const int reps = 1000;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, 0, d, f, 0x1234567ull);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double cyc = ms / reps * 1e-3 * 2.4e9 / ((double)blocksPerCU * 2 * 32 * ITER);
+  printf("%-28s blocks/CU=%d lds=%3zuK sustained (3000 + 1000 launches back to back) %7.4f ms/launch  %7.2f cyc/butterfly/SIMD (2.4GHz nominal)\\n",
+         name, blocksPerCU, lds >> 10, ms / reps, cyc);
+  return 0;
+}
+int main() {
+  u64 *d; CHECK(hipMalloc(&d, (size_t)256 * 4 * 512 * 16 * 8));
+  std::vector<u64> ref, got;
+  for (int pass = 0; pass < 2; ++pass) {
+    const size_t lds = pass == 0 ? 64 * 1024 : 0;
+    const int bpc = pass == 0 ? 2 : 4;
+    if (timeit("hipcc C++ (cndmask)", k_cxx, d, bpc, lds, &ref)) return 1;
+#define RUN(K) if (timeit(#K, K, d, bpc, lds, &got)) return 1; { size_t bad = 0; for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != got[i]; printf("   vs C++: %zu mismatches of %zu\\n", bad, ref.size()); }
+    RUN(k_asm_chain_w4) RUN(k_asm_prime_w4)
+    for (int round = 0; round < 2; ++round) {
+      if (sustained("k_asm_chain_w4", k_asm_chain_w4, d, bpc, lds)) return 1;
+      if (sustained("k_asm_prime_w4", k_asm_prime_w4, d, bpc, lds)) return 1;
+    }
+  }
+  return 0;
+}''')
+        return
     for W in (1, 2, 4):
         print(kernel(W))
         print()
