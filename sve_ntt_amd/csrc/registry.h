@@ -5,6 +5,8 @@
 // (tests/cpu_sim/sim.cpp; test-only, never linked into the product).
 #pragma once
 
+#include <cstdlib>
+
 #include "tile_ntt.h"
 
 namespace sventt_hip {
@@ -72,6 +74,12 @@ constexpr int SLIM_F0 = 2;
 template <int LOGL, int MODE, int ARITH = ARITH_MONT, bool TWOLVL = false>
 using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
                             typename DefaultSteps<LOGL>::type, ARITH, TWOLVL>;
+// Thin COL tiles (T = 2, 16-byte segments): a quarter of the wide tile's LDS, 2^11 columns in 256 threads --
+// four independent workgroups per CU instead of two (experiment, SVENTT_COL_THIN=1).
+constexpr int THIN_F0 = 1;
+template <int LOGL, int MODE, int ARITH = ARITH_MONT>
+using ColTileThin = TileNTT<LOGL + THIN_F0, THIN_F0, LOGL, REG_LOGE, MODE, true,
+                            typename DefaultSteps<LOGL>::type, ARITH>;
 // Two-level variants of both (tile_ntt.h: TWOLVL): the first pass of the sharded row transform when it
 // is longer than the rank count, i.e. the gather of the received pieces fused with the column pass
 // that used to follow it.  Lengths 2^2 .. 2^12 (rank count x inner column length).
@@ -206,6 +214,9 @@ const Entry *find_kernel_in_registry(int kind, int logl, int dir, int flag, int 
       SVENTT_A_COL(ColTile2L, 8), SVENTT_A_COL(ColTile2L, 9), SVENTT_A_COL(ColTile2L, 10),
       SVENTT_A_COL(ColTile2L, 11),
       SVENTT_A_COL(ColTileSlim2L, 10), SVENTT_A_COL(ColTileSlim2L, 11), SVENTT_A_COL(ColTileSlim2L, 12),
+#if defined(SVENTT_WITH_THIN)
+      SVENTT_A_COL(ColTileThin, 11), SVENTT_A_COL(ColTileThin, 12),
+#endif
       SVENTT_FINE_ROW_ENTRIES(1), SVENTT_FINE_ROW_ENTRIES(2), SVENTT_FINE_ROW_ENTRIES(3),
       SVENTT_FINE_ROW_ENTRIES(4), SVENTT_FINE_ROW_ENTRIES(5), SVENTT_FINE_ROW_ENTRIES(6),
       SVENTT_FINE_ROW_ENTRIES(7), SVENTT_FINE_ROW_ENTRIES(8), SVENTT_FINE_ROW_ENTRIES(9),
@@ -256,6 +267,9 @@ const Entry *find_arith_kernel_in_registry(int kind, int logl, int dir, int flag
 // log2 of the tile width for a column pass of length 2^logl over 2^logs columns
 // (-1: fewer columns than the narrowest tile).
 inline int registry_col_f0(int logl, int logs, bool slim = false) {
+#if defined(SVENTT_WITH_THIN)
+  if (std::getenv("SVENTT_COL_THIN") && logl >= 11 && logl <= 12 && logs >= THIN_F0) return THIN_F0;
+#endif
   if (slim && logl >= 10 && logl <= 12 && logs >= SLIM_F0) return SLIM_F0;
   if (logl > 11) return -1;
   if (logs >= col_f0(logl)) return col_f0(logl);

@@ -98,3 +98,24 @@ for inverse in (False, True):
         print(f"  CUs seen: {len(np.unique(key))}; workgroup duration mean {(wg_end - wg_start).mean():.2f} us; "
               f"end of a workgroup's stream -> first stamp of its successor on that CU: median {np.median(gaps):.2f} us, "
               f"p10 {np.percentile(gaps, 10):.2f}, p90 {np.percentile(gaps, 90):.2f}")
+
+        # How many of a CU's 16 resident waves are in a butterfly phase (compute + out) at a time: s_memtime is
+        # common to the CUs of an XCD, so the stamps of a CU's waves are comparable.  Phase-locked workgroups
+        # (both loading, then both computing) show up as time with few computing waves.
+        wave_key = np.repeat(key, 8)
+        hist = np.zeros(17)
+        span_ticks = 0.0
+        for k in np.unique(key):
+            w = np.where(wave_key == k)[0]
+            lo, hi = t[w, 0].min(), t[w, 30].max()
+            grid = np.linspace(lo, hi, 400)
+            busy = np.zeros(len(grid), dtype=np.int64)
+            for s in range(steps):
+                a0, a1 = t[w, 6 * s + 3], t[w, 6 * s + 5]
+                busy += ((grid[None, :] >= a0[:, None]) & (grid[None, :] < a1[:, None])).sum(axis=0)
+            hist += np.bincount(np.minimum(busy, 16), minlength=17)
+            span_ticks += hi - lo
+        hist /= hist.sum()
+        print("  share of a CU's time with n waves in a butterfly phase (of 16 resident): "
+              f"n=0: {hist[0]:.3f}, 1-4: {hist[1:5].sum():.3f}, 5-8: {hist[5:9].sum():.3f}, 9-12: {hist[9:13].sum():.3f}, "
+              f"13-16: {hist[13:].sum():.3f}; mean {np.dot(hist, np.arange(17)):.2f}")
