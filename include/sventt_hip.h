@@ -152,15 +152,20 @@ int sventt_run_pass(const sventt_plan *plan, int inverse, int pass_index,
  *      goes to rank h; the receive buffer is recv[s][q][c] (source rank s, local
  *      row q, column c < Cl);
  *   3. the passes of the ROWS plan, sventt_run_pass(rows, 0, i, ...): pass 0
- *      reads `recv` and writes whole rows to `out` (it is the first, length-nranks,
- *      column pass of the length-C row transform and gathers the pieces on the
- *      fly -- no separate transposition), the remaining passes run in place on
- *      `out`.
+ *      reads `recv` and writes whole rows to `out`.  It is the first column pass
+ *      of the length-C row transform, nranks * 2^k long: row s * 2^k + i' of its
+ *      blocks is row i' of the piece received from rank s (a two-level stride),
+ *      so the pieces are gathered on the fly -- no transposition and no sweep of
+ *      its own (r02 gathered in a length-nranks pass; N = 2^30 on 8 ranks is now
+ *      col 2^11 | exchange | col 2^7 | row 2^12: three sweeps of a rank's data).
+ *      The remaining passes run in place on `out`.
  * Inverse = the mirror: rows passes 0..k-2 in place on the rows buffer, the last
  * rows pass writes piece layout, all-to-all back, then
  * sventt_sharded_columns(cols, 1, ...) which also applies the 1/n scaling.
  * Both plans take device pointers only and run through the entry points named
- * here (sventt_forward/inverse refuse them).
+ * here (sventt_forward/inverse refuse them).  nranks is a power of two >= 1; one
+ * rank (the exchange is with itself) runs the same pipeline on one GPU and needs
+ * C >= 2^14.  r_log2 <= 12.
  */
 int sventt_sharded_plan_create(uint64_t p, uint64_t g, uint64_t n,
                                uint32_t r_log2, int rank, int nranks,
@@ -173,16 +178,20 @@ int sventt_sharded_columns(const sventt_plan *plan, int inverse,
 
 /*
  * Pipelining the exchange.  A column pass (pass_index must name one) can be run on
- * chunk `chunk` of `nchunks` equal column ranges at a time, so that the all-to-all
- * of one chunk overlaps the passes of its neighbours.  A side marked compact is a
- * buffer holding only that chunk's columns (leading dimensions divided by nchunks,
- * column index restarting at 0):
+ * chunk `chunk` of `nchunks` at a time, so that the all-to-all of one chunk overlaps
+ * the passes of its neighbours.  The chunks are equal column ranges -- of the whole
+ * block, or, for the column plan when the rows plan starts with a 2^k > 1 rows-per-piece
+ * pass, of each of the 2^k runs of Cl / 2^k columns (that pass needs columns c, c + Cl/2^k,
+ * ... of every piece together; the two plans agree on this by construction).  A side marked
+ * compact is a buffer holding only that chunk's columns, run after run (leading dimensions
+ * divided by nchunks, column index restarting at 0):
  *   forward: column plan pass 0, dst compact  -> work_k = R x (Cl/nchunks), whose row
  *            blocks are the all-to-all chunks; rows plan pass 0, src compact, reads the
  *            received recv_k[s][q][Cl/nchunks] and writes whole rows;
  *   inverse: rows plan last pass with dst compact, column plan pass 0 with src compact.
  */
-/* Column tiles per block of a column pass (0 for a row pass): nchunks must divide it. */
+/* Column tiles per block (per run, see above) of a column pass, 0 for a row pass: nchunks
+ * must divide it (a power of two). */
 uint64_t sventt_plan_pass_tiles_per_block(const sventt_plan *plan, int inverse,
                                           int pass_index);
 int sventt_run_pass_chunk(const sventt_plan *plan, int inverse, int pass_index,
@@ -205,8 +214,13 @@ int sventt_run_pass_chunk(const sventt_plan *plan, int inverse, int pass_index,
  *
  * sventt_sharded_forward / _inverse: the exchange is ncclSend / ncclRecv between
  * ncclGroupStart / ncclGroupEnd on `nccl_comm` (an ncclComm_t of `nranks` ranks in which this
- * process has the plans' rank); librccl is loaded on first use (dlopen), the library does not
- * link it.  The *_transport variants take the exchange as a callback instead (MPI, a test
+ * process has the plans' rank); librccl is loaded on first use (dlopen), the library neither
+ * links it nor needs its headers.  WHAT HAS RUN: this path has executed on hardware with a
+ * ONE-rank communicator only (tests/cpp/rccl_one_rank.cpp: the group of ncclSend/ncclRecv to
+ * itself on the communication stream, ordered against the kernels by the same events, results
+ * == oracle); with several ranks it is unmeasured -- no multi-GPU node was available -- and
+ * only the loopback transport has carried N = 2^30 over 8 ranks (tests/cpp/sharded_driver.cpp).
+ * The *_transport variants take the exchange as a callback instead (MPI, a test
  * loopback, another collective library):
  *   all_to_all(ctx, send, recv, count, stream): piece h of `send` (count words each) goes to
  *   rank h, piece s of `recv` comes from rank s; enqueue on `stream` (it may also block).

@@ -44,6 +44,10 @@ template <> struct RowSteps<4> { using type = Steps<3, 1>; };
 template <> struct RowSteps<7> { using type = Steps<4, 2, 1>; };
 template <> struct RowSteps<8> { using type = Steps<4, 3, 1>; };
 template <> struct RowSteps<11> { using type = Steps<4, 4, 2, 1>; };
+#if SVENTT_PAIR
+// first step radix-8 on two neighbouring elements (16-byte loads), last step radix-4 (32 bytes per lane)
+template <> struct RowSteps<13> { using type = Steps<3, 4, 4, 2>; };
+#endif
 
 constexpr int REG_LOGE = 4;
 // ROW tiles are 2^12 elements (256 threads) unless the row itself is longer.

@@ -49,6 +49,12 @@ enum : int { MODE_FWD = 0, MODE_INV = 1 };
 // stores.  VALU issue goes to the highest priority, then to the oldest wave: a workgroup that has just
 // started is the youngest on its SIMDs and computes its load addresses in whatever slots the
 // other workgroup's butterflies leave (A/B: profiles/r03/asm_stages_ab.txt).
+// Paired sets (experiment, -DSVENTT_PAIR=1): in a radix-8 step that touches HBM the thread's two sets are
+// made the two NEIGHBOURING elements (ROW) / columns (COL), so that each of its eight accesses moves
+// 16 bytes instead of 8 (half the vector-memory instructions; profiles/r03/asm_stages_ab.txt).
+#ifndef SVENTT_PAIR
+#define SVENTT_PAIR 0
+#endif
 #ifndef SVENTT_PRIO_LOAD
 #define SVENTT_PRIO_LOAD 0
 #endif
@@ -218,9 +224,21 @@ struct TileNTT {
   template <int SI> static constexpr bool chunk_preserving() {
     return NT <= 64 || (F0 + LOGL - STEPS::sum(SI)) <= LOGT - WB;
   }
+  // (see SVENTT_PAIR) a radix-8 step of an E = 16 tile whose two sets are bit 0 of the tile index
+  template <int SI> static constexpr bool pair_sets() {
+    constexpr bool from_hbm = (MODE == MODE_FWD) ? (SI == 0) : (SI == NSTEPS - 1);
+    constexpr bool to_hbm = (MODE == MODE_FWD) ? (SI == NSTEPS - 1) : (SI == 0);
+    return SVENTT_PAIR != 0 && LOGE == 4 && STEPS::k[SI] == 3 && (from_hbm || to_hbm) && !TWOLVL &&
+           (COL || LOGT == LOGL) && F0 + LOGL - STEPS::sum(SI) - 3 >= 1;
+  }
   template <int SI> F64_HD static u32 set_number(u32 tid, int g) {
     constexpr int k = STEPS::k[SI];
-    if constexpr (NT > 64 && chunk_preserving<SI>())
+    if constexpr (pair_sets<SI>()) {
+      if constexpr (NT > 64 && chunk_preserving<SI>())
+        return ((tid >> 6) << (LOGT - k - WB)) | ((tid & 63u) << 1) | (u32)g;
+      else
+        return (tid << 1) | (u32)g;
+    } else if constexpr (NT > 64 && chunk_preserving<SI>())
       return ((tid >> 6) << (LOGT - k - WB)) | ((u32)g << 6) | (tid & 63u);
     else
       return tid + (u32)g * NT;
@@ -406,6 +424,10 @@ struct TileNTT {
       const u32 e = twist_e0(col, I0[g]) + col * twist_bv(v, LO);
       const u64 *lo = a.twist_lo + (size_t)(e & ((1u << a.twist_shift) - 1u)) * TWW;
       const u64 *hi = a.twist_hi + (size_t)(e >> a.twist_shift) * TWW;
+#if defined(SVENTT_STUB_TWIST)  // analysis builds only: what the scattered twist-table loads cost (wrong results)
+      f.l[q] = (u64)(uintptr_t)lo | 1u, f.h[q] = (u64)(uintptr_t)hi | 1u;
+      if constexpr (TWW == 2) f.lp[q] = f.l[q], f.hp[q] = f.h[q];
+#else
       if constexpr (TWW == 2) {
         const ulonglong2 lv = *reinterpret_cast<const ulonglong2 *>(lo);
         const ulonglong2 hv = *reinterpret_cast<const ulonglong2 *>(hi);
@@ -413,6 +435,7 @@ struct TileNTT {
       } else {
         f.l[q] = lo[0], f.h[q] = hi[0];
       }
+#endif
     }
     return f;
   }
@@ -567,6 +590,16 @@ struct TileNTT {
       w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
     }
     // ---- gather ------------------------------------------------------------
+    if constexpr (from_hbm && pair_sets<SI>()) {
+      // the two sets are neighbours in memory: eight 16-byte loads
+      const u64 vstride = COL ? (a.src_istride << LO) : (1ull << lo);
+      const u64 *p0 = a.src + saddr(a, t, I0[0]);
+#pragma unroll
+      for (int v = 0; v < R; ++v) {
+        const ulonglong2 two = *reinterpret_cast<const ulonglong2 *>(p0 + src_off<LO>(a, v, vstride));
+        x[v] = two.x, x[R + v] = two.y;
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if constexpr (from_hbm) {
@@ -630,7 +663,16 @@ struct TileNTT {
         MontGroup<2>::run(x, o2.v[0], o2.v[1], o2.v[2], o2.v[3], zr, c);
         MontGroup<3>::run(x, o3.v[0], o3.v[1], o3.v[2], o3.v[3], zr, c);
       }
-      if constexpr (!early) {
+      if constexpr (!early && pair_sets<SI>()) {
+        const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
+        u64 *p0 = a.dst + gaddr(a, t, I0[0]);
+#pragma unroll
+        for (int v = 0; v < R; ++v) {
+          ulonglong2 two;
+          two.x = x[v], two.y = x[R + v];
+          *reinterpret_cast<ulonglong2 *>(p0 + dst_off<LO>(a, v, vstride)) = two;
+        }
+      } else if constexpr (!early) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const u64 vstride = COL ? (a.istride << LO) : (1ull << lo);
