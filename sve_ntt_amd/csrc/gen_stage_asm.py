@@ -17,6 +17,14 @@ so that every dependent instruction has three independent ones in front of it.
 Arithmetic is exactly csrc/field64.h's (montmul / addmod / submod / butterfly_fwd / butterfly_inv):
 same values in, same canonical values out; tests compare the kernels with the oracle bit for bit.
 
+EXEC invariant.  Every statement narrows EXEC for its corrections and restores it from `c.save`, the
+EXEC read once at the entry of TileNTT::step_asm -- NOT from the EXEC it found ("exec" is not in the
+clobber lists: hipcc would have to re-materialise it around ~140 statements per kernel).  That is
+correct because every statement runs in the kernel's uniform control flow: a workgroup either
+returns whole (tile_kernel: !t.live) or runs every step with all lanes; loads are selected, not
+branched around, and the only divergent regions are plain C++ stores behind in_range() -- no asm
+statement may ever be placed inside one.  tile_ntt.h repeats this where the statements are used.
+
 Register map (per thread): data v0..v31; slot s of an asm statement uses v[32+12s .. 43+12s] and
 s[60+4s .. 63+4s]; vcc is the unused carry-out of v_mad_u64_u32.  All of them are declared clobbered.
 """

@@ -549,6 +549,9 @@ struct TileNTT {
     constexpr bool twist_in = COL && FLAG && MODE == MODE_INV && from_hbm;
     constexpr bool twist_out = COL && FLAG && MODE == MODE_FWD && to_hbm;
     constexpr bool multiply_out = !COL && FLAG && MODE == MODE_FWD && to_hbm;
+    // c.save: EXEC on entry = all lanes of a live workgroup.  The assembly groups restore EXEC from it after
+    // their masked corrections, so they must stay in uniform control flow: never inside a divergent branch
+    // (gen_stage_asm.py: "EXEC invariant").
     const AsmConsts c{a.f.N, a.f.negN, (u32)a.f.N, (u32)(a.f.N >> 32), (u32)a.f.Ninv,
                       (u32)(a.f.Ninv >> 32), __builtin_amdgcn_read_exec(), (u32)a.f.negN,
                       (u32)(a.f.negN >> 32)};
