@@ -507,6 +507,57 @@ def test_device_pointers_flag(eng, port):
     assert ntt._lib.sventt_plan_device(ntt._h) == torch.cuda.current_device()
 
 
+def test_plan_refuses_every_launch_from_another_device(eng):
+    """include/sventt_hip.h "Threads and devices" (ADVICE r02): a plan belongs to the device it was
+    created on; EVERY entry point that launches on its behalf -- not only sventt_forward/inverse --
+    must return SVENTT_ERR_INVALID_ARGUMENT from a thread whose current device is another one, instead
+    of launching there with tables that live elsewhere.  Needs two visible devices (skips on the
+    one-GPU test box; an 8-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    from sve_ntt_amd import _lib
+    m = 1 << 14
+    torch.cuda.set_device(0)
+    ntt = eng.NTT(eng.Modulus(P, G), m, device_pointers=True)
+    x = torch.zeros(m, dtype=torch.int64, device="cuda:0")
+    y = torch.zeros(m, dtype=torch.int64, device="cuda:0")
+    L, h = ntt._lib, ntt._h
+    try:
+        torch.cuda.set_device(1)
+        bad = _lib.SVENTT_ERR_INVALID_ARGUMENT
+        assert L.sventt_forward(h, y.data_ptr(), x.data_ptr(), None) == bad
+        assert L.sventt_run_pass(h, 0, 0, y.data_ptr(), x.data_ptr(), None) == bad
+        assert L.sventt_pointwise_multiply(h, y.data_ptr(), x.data_ptr(), x.data_ptr(), m, None) == bad
+        assert L.sventt_to_montgomery(h, y.data_ptr(), x.data_ptr(), m, None) == bad
+        assert L.sventt_from_montgomery(h, y.data_ptr(), x.data_ptr(), m, None) == bad
+        assert L.sventt_forward_multiply(h, y.data_ptr(), x.data_ptr(), x.data_ptr(), None) == bad
+        assert b"current device" in L.sventt_last_error()
+    finally:
+        torch.cuda.set_device(0)
+    assert L.sventt_forward(h, y.data_ptr(), x.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+
+
+def test_failed_host_register_leaves_no_sticky_error(eng, port):
+    """sventt_host_register is used best-effort (PageMemory); a failing hipHostRegister must
+    not leave HIP's per-thread last error behind for the next launch to report as its own."""
+    from sve_ntt_amd import _lib
+    L = _lib.load()
+    buf = np.zeros(1 << 12, dtype=np.uint64)
+    assert L.sventt_host_register(buf.ctypes.data, buf.nbytes) == 0
+    assert L.sventt_host_register(buf.ctypes.data, buf.nbytes) != 0      # already registered: fails
+    m = 1 << 12
+    ntt = eng.NTT(eng.Modulus(P, G), m)
+    src = port.fill_splitmix(m, 5, P)
+    out = torch.empty(m, dtype=torch.int64, device="cuda")
+    ntt.compute_forward(out, dev(src))                                     # must not see the stale error
+    assert np.array_equal(host(out), port.forward(src, P, G))
+    assert L.sventt_host_unregister(buf.ctypes.data) == 0
+    assert L.sventt_host_unregister(buf.ctypes.data) != 0                  # not registered any more
+    ntt.compute_forward(out)
+    torch.cuda.synchronize()
+
+
 def test_sharded_columns_entry_point_equals_chunked_path(eng):
     """sventt_sharded_columns (the one-call column phase a C/C++ host would use) writes exactly
     what the Python driver's single-chunk sventt_run_pass_chunk call writes, both directions."""
