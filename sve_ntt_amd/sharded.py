@@ -9,9 +9,14 @@ global transpose), and the row transforms split by row block:
       in : columns [k*C/G, (k+1)*C/G)  as an R x (C/G) slab
       1. local column pass (length R, six-step twiddle with the global column index)
       2. dist.all_to_all_single          (RCCL; contiguous row blocks, no packing)
-      3. local row passes; the first one is the length-G column pass of the row
-         transform and reads the received pieces in place of a transposition
+      3. local row passes; the first one is the first column pass of the length-C row
+         transform (G * 2^k long) and reads the received pieces through a two-level
+         stride in place of a transposition -- no gather sweep (csrc/plan_core.h:
+         sharded_row_split); N = 2^30 on 8 ranks: col 2^11 | exchange | col 2^7 | row 2^12
       out: rows [k*R/G, (k+1)*R/G) = slice k of the bit-reversed result
+
+Callers that hold the natural-order vector as contiguous chunks use forward_natural /
+inverse_natural (one more exchange up front).
 
 Steps 1-3 are PIPELINED over ``chunks`` column ranges: the column pass writes
 chunk j compactly, its all-to-all is started asynchronously, the column pass of
@@ -207,6 +212,54 @@ class ShardedNTT:
             e.columns_chunk(True, dst, self._piece(self._back, k), k, K)
         self._mark(events, 2 + n_in_place)
         return dst
+
+
+    # ---- callers whose data is sharded the natural way -------------------------------------------
+    # forward()/inverse() take the natural-order side as a COLUMN slab (what the six-step's first
+    # phase needs).  A caller that holds the natural-order vector as contiguous chunks -- rank k has
+    # elements [k*n/G, (k+1)*n/G), i.e. rows [k*R/G, (k+1)*R/G) of the R x C matrix -- pays one more
+    # exchange ("if the caller's input is row-sharded a second all-to-all is needed up
+    # front"): every rank cuts its rows into G column blocks, block h goes to rank h, and what arrives
+    # IS the slab (piece s = rows [s*R/G, (s+1)*R/G) of it), no reordering on the receiving side.
+    def slab_from_natural(self, chunk, out=None):
+        """this rank's contiguous n/G elements of the natural-order vector -> its R x (C/G) column slab"""
+        import torch
+        G = self.world
+        R = 1 << self.r_log2
+        Rl, Cl = R // G, (self.n // R) // G
+        packed = chunk.view(Rl, G, Cl).permute(1, 0, 2).contiguous().view(-1)   # [h][q][c']
+        out = torch.empty_like(packed) if out is None else out
+        w = self._exchange(out, packed)
+        if w is not None:
+            w.wait()
+        return out
+
+    def natural_from_slab(self, slab, out=None):
+        """the inverse redistribution: column slab -> this rank's contiguous chunk of the natural-order vector"""
+        import torch
+        G = self.world
+        R = 1 << self.r_log2
+        Rl, Cl = R // G, (self.n // R) // G
+        recv = torch.empty_like(slab)
+        w = self._exchange(recv, slab.contiguous())      # piece h of the slab (rows of rank h) -> rank h
+        if w is not None:
+            w.wait()
+        res = recv.view(G, Rl, Cl).permute(1, 0, 2).contiguous().view(-1)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def forward_natural(self, dst, src_chunk):
+        """natural-order contiguous chunk -> bit-reversed contiguous chunk (two exchanges)"""
+        return self.forward(dst, self.slab_from_natural(src_chunk))
+
+    def inverse_natural(self, dst_chunk, src):
+        """bit-reversed contiguous chunk -> natural-order contiguous chunk (two exchanges)"""
+        import torch
+        slab = torch.empty_like(src)
+        self.inverse(slab, src)
+        return self.natural_from_slab(slab, dst_chunk)
 
 
 def batch_partition(batch: int, world: int, rank: int) -> tuple[int, int]:

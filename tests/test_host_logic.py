@@ -124,11 +124,23 @@ def test_plan_shapes():
     # config #4: one workgroup per N = 2^12 transform
     s = simlib.plan_shape(P, G, 1 << 12, batch=1 << 16)
     assert [(x["kind"], x["logl"], x["grid"]) for x in s] == [(0, 12, 1 << 16)]
-    for logn in range(1, 28):
+    for logn in range(1, 32):
         for inv in (False, True):
             s = simlib.plan_shape(P, G, 1 << logn, inverse=inv)
             assert sum(x["logl"] for x in s) == logn
             assert all(x["logl"] <= (12 if x["kind"] == 1 else 13) for x in s)
+    # three passes (out of the Infinity Cache): the split comes from the measured per-pass costs
+    # (plan_core.h: large_pass_cost) -- a short, wide first pass (address translation), then the rest
+    want = {26: [7, 7, 12], 27: [7, 8, 12], 28: [7, 8, 13], 30: [7, 11, 12], 31: [7, 11, 13]}
+    for logn, lens in want.items():
+        s = simlib.plan_shape(P, G, 1 << logn)
+        assert [x["logl"] for x in s] == lens, (logn, s)
+        assert s[0]["f0"] == 5  # 32 columns = 256-byte row segments
+        back = simlib.plan_shape(P, G, 1 << logn, inverse=True)
+        assert [x["logl"] for x in back] == lens[::-1]
+    # two-pass plans over more than 2^26 elements prefer a 2^12 row pass (large batches, sharded row phases)
+    assert [x["logl"] for x in simlib.plan_shape(P, G, 1 << 19, batch=1 << 8)] == [7, 12]
+    assert [x["logl"] for x in simlib.plan_shape(P, G, 1 << 19, batch=1 << 4)] == [6, 13]
 
 
 def test_planner_errors():

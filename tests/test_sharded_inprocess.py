@@ -92,6 +92,47 @@ def run_case(world, log2n, r_log2, chunks, seed):
     return results[0][3]
 
 
+@pytest.mark.parametrize("world,log2n,r_log2,chunks", [(2, 14, 3, 2), (4, 16, 6, 1), (8, 18, 6, 4)])
+def test_naturally_sharded_callers(world, log2n, r_log2, chunks):
+    """forward_natural / inverse_natural: every rank holds a CONTIGUOUS chunk of the natural-order vector
+    (a row-sharded caller needs one more exchange up front) and gets its contiguous chunk
+    of the bit-reversed result; the inverse returns the input chunk."""
+    port = oracle.port()
+    n = 1 << log2n
+    full = port.fill_splitmix(n, 77, P)
+    want = port.forward(full, P, G)
+    dist = ThreadDist(world)
+    share = n // world
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            dist.bind(rank)
+            engine = SimShardEngine(eng.BASELINE_MODULUS, n, r_log2, rank, world)
+            sh = ShardedNTT(eng.BASELINE_MODULUS, n, dist, r_log2=r_log2, engine=engine, device="cpu", chunks=chunks)
+            mine = torch.from_numpy(full[rank * share:(rank + 1) * share].view(np.int64).copy())
+            out = torch.full_like(mine, 0x5555555555555555)
+            sh.forward_natural(out, mine)
+            back = torch.full_like(mine, 0x5555555555555555)
+            sh.inverse_natural(back, out)
+            results[rank] = (out.numpy().view(np.uint64), back.numpy().view(np.uint64))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+            dist.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for rank in range(world):
+        fwd, back = results[rank]
+        assert np.array_equal(fwd, want[rank * share:(rank + 1) * share]), ("forward", rank)
+        assert np.array_equal(back, full[rank * share:(rank + 1) * share]), ("inverse", rank)
+
+
 def test_random_sharded_shapes_in_process():
     rng = np.random.default_rng(2024)
     done = 0
