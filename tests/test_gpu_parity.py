@@ -507,6 +507,38 @@ def test_device_pointers_flag(eng, port):
     assert ntt._lib.sventt_plan_device(ntt._h) == torch.cuda.current_device()
 
 
+def test_transforms_are_capturable_in_a_hip_graph(eng, port):
+    """Launch-bound callers (many small transforms, BASELINE configs[1]) can capture the library's launches
+    in a HIP graph and replay them: after a plan's first call nothing in sventt_forward/inverse
+    synchronises or allocates."""
+    m = 1 << 17
+    ntt = eng.NTT(eng.Modulus(P, G), m, n0_log2=8, device_pointers=True)
+    src_h = port.fill_splitmix(m, 21, P)
+    want = port.forward(src_h, P, G)
+    src = dev(src_h)
+    outs = [torch.empty_like(src) for _ in range(4)]
+    back = torch.empty_like(src)
+    ntt.compute_forward(outs[0], src)
+    ntt.compute_inverse(back, outs[0])
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for o in outs:
+                ntt.compute_forward(o, src, stream=s)
+            ntt.compute_inverse(back, outs[3], stream=s)
+    for o in outs:
+        o.zero_()
+    back.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(host(o), want)
+    assert np.array_equal(host(back), src_h)
+
+
 def test_plan_refuses_every_launch_from_another_device(eng):
     """include/sventt_hip.h "Threads and devices" (ADVICE r02): a plan belongs to the device it was
     created on; EVERY entry point that launches on its behalf -- not only sventt_forward/inverse --
@@ -545,7 +577,8 @@ def test_failed_host_register_leaves_no_sticky_error(eng, port):
     L = _lib.load()
     buf = np.zeros(1 << 12, dtype=np.uint64)
     assert L.sventt_host_register(buf.ctypes.data, buf.nbytes) == 0
-    assert L.sventt_host_register(buf.ctypes.data, buf.nbytes) != 0      # already registered: fails
+    assert L.sventt_host_register(0x10000, 1 << 16) != 0                   # not mapped: hipHostRegister fails
+    assert b"hipHostRegister" in L.sventt_last_error()
     m = 1 << 12
     ntt = eng.NTT(eng.Modulus(P, G), m)
     src = port.fill_splitmix(m, 5, P)
@@ -553,9 +586,10 @@ def test_failed_host_register_leaves_no_sticky_error(eng, port):
     ntt.compute_forward(out, dev(src))                                     # must not see the stale error
     assert np.array_equal(host(out), port.forward(src, P, G))
     assert L.sventt_host_unregister(buf.ctypes.data) == 0
-    assert L.sventt_host_unregister(buf.ctypes.data) != 0                  # not registered any more
+    assert L.sventt_host_unregister(0x10000) != 0                          # never registered
     ntt.compute_forward(out)
     torch.cuda.synchronize()
+    assert np.array_equal(host(out), port.forward(port.forward(src, P, G), P, G))
 
 
 def test_sharded_columns_entry_point_equals_chunked_path(eng):
