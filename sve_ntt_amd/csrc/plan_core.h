@@ -282,8 +282,13 @@ inline int large_pass_cost(int where, int logl) {
 // pass <= MAX_ROW_LOGL.  n0_log2 (if non-zero) fixes the first COL pass (the R
 // of the reference's n = R x C six-step, kernel/recursive.hpp:61-75).
 // `large`: the whole array (n * batch) does not fit the Infinity Cache (>= 2^26 elements).
+// `mid_rows12`: a single transform of 2^22 points (both directions) or 2^23 points (forward) runs with
+// a 2^12 row pass (four workgroups per CU) and the 2^10 / 2^11 x T4 column pass instead of the longest
+// row: 60.9 against 62.7 us and 101.8 against 106.7 us (tools/split2_search.py, profiles/r03/
+// split2_search.txt; the inverse of 2^23 is 2.5 % slower that way and keeps 2^10 | 2^13 -- the two
+// directions of a plan need not use the same split).
 inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row, std::string &err,
-                        bool fine = false, bool large = false) {
+                        bool fine = false, bool large = false, bool mid_rows12 = false) {
   cols.clear();
   if (fine) {  // at most two passes; the caller checked that the fine tiles cover the shape
     const int c = n0_log2 ? (int)n0_log2 : (logn <= MAX_FINE_ROW_LOGL ? 0 : logn / 2);
@@ -356,6 +361,7 @@ inline int choose_split(int logn, u32 n0_log2, std::vector<int> &cols, int &row,
       large_pass_cost(1, rem - (MAX_ROW_LOGL - 1)) + large_pass_cost(2, MAX_ROW_LOGL - 1) <
           large_pass_cost(1, rem - MAX_ROW_LOGL) + large_pass_cost(2, MAX_ROW_LOGL))
     row = MAX_ROW_LOGL - 1;
+  if (mid_rows12 && n0_log2 == 0) row = MAX_ROW_LOGL - 1;
   if (row > rem - 1) row = rem - 1;
   rem -= row;
   // (2^25 = 2^12 x 2^13 in two passes beats three: 581 vs 624 us forward, r01)
@@ -482,7 +488,14 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
     pl.fine = (int)n0_log2 < logn && (int)n0_log2 <= MAX_FINE_COL_LOGL &&
               logn - (int)n0_log2 <= MAX_FINE_ROW_LOGL &&
               registry_fine_col_f0((int)n0_log2, logn - (int)n0_log2) >= 0;
-  if ((rc = choose_split(logn, n0_log2, cols, row, err, pl.fine, pl.total >= (1ull << 26)))) return rc;
+  const bool large = pl.total >= (1ull << 26);
+  if ((rc = choose_split(logn, n0_log2, cols, row, err, pl.fine, large,
+                         batch == 1 && !pl.fine && (logn == 22 || logn == 23))))
+    return rc;
+  std::vector<int> icols;  // the inverse plan's own split (mirrored below)
+  int irow = 0;
+  if ((rc = choose_split(logn, n0_log2, icols, irow, err, pl.fine, large, batch == 1 && !pl.fine && logn == 22)))
+    return rc;
   const u64 divisor = inverse_divisor ? inverse_divisor % p : n % p;
   if (divisor == 0) {
     err = "inverse divisor is a multiple of the modulus";
@@ -507,20 +520,20 @@ inline int build_plan(HostPlan &pl, u64 p, u64 g, u64 n, u32 n0_log2, u64 batch,
   }
   if (flags & PLAN_INVERSE) {
     // mirror: ROW first, then the COL passes innermost -> outermost
-    if (row > 0) {
+    if (irow > 0) {
       pl.inv.emplace_back();
-      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_ROW, row, 1, true, cols.empty(),
-                               cols.empty() ? ninv : 1, 0, 0, err)))
+      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_ROW, irow, 1, true, icols.empty(),
+                               icols.empty() ? ninv : 1, 0, 0, err)))
         return rc;
     }
-    int rem = row;
-    for (size_t k = cols.size(); k-- > 0;) {
+    int rem = irow;
+    for (size_t k = icols.size(); k-- > 0;) {
       pl.inv.emplace_back();
       const bool outermost = (k == 0);
-      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_COL, cols[k], 1ull << rem, true, true,
-                               outermost ? ninv : 1, 0, rem + cols[k], err)))
+      if ((rc = make_host_pass(pl, pl.inv.back(), KIND_COL, icols[k], 1ull << rem, true, true,
+                               outermost ? ninv : 1, 0, rem + icols[k], err)))
         return rc;
-      rem += cols[k];
+      rem += icols[k];
     }
   }
   return PLAN_OK;
