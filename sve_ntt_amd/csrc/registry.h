@@ -30,7 +30,14 @@ template <> struct DefaultSteps<7> { using type = Steps<4, 3>; };
 template <> struct DefaultSteps<8> { using type = Steps<4, 4>; };
 template <> struct DefaultSteps<9> { using type = Steps<4, 4, 1>; };
 template <> struct DefaultSteps<10> { using type = Steps<4, 4, 2>; };
-template <> struct DefaultSteps<11> { using type = Steps<4, 4, 3>; };
+// 2^11 (the column tile of the 2^24 plan): radix-8 in the middle.  r03 A/B over eight alternating rounds and
+// a duplicate baseline (profiles/r03/asm_stages_ab.txt (5)): <4,3,4> 99.7-103.0 us against <4,4,3> 103.6-106.0
+// forward, 104.5-106.0 against 106.7-107.2 inverse.  -DSVENTT_COL11_STEPS=4,4,3 rebuilds r02's order.
+#if defined(SVENTT_COL11_STEPS)
+template <> struct DefaultSteps<11> { using type = Steps<SVENTT_COL11_STEPS>; };
+#else
+template <> struct DefaultSteps<11> { using type = Steps<4, 3, 4>; };
+#endif
 template <> struct DefaultSteps<12> { using type = Steps<4, 4, 4>; };
 template <> struct DefaultSteps<13> { using type = Steps<4, 4, 4, 1>; };
 
@@ -44,9 +51,20 @@ template <> struct RowSteps<4> { using type = Steps<3, 1>; };
 template <> struct RowSteps<7> { using type = Steps<4, 2, 1>; };
 template <> struct RowSteps<8> { using type = Steps<4, 3, 1>; };
 template <> struct RowSteps<11> { using type = Steps<4, 4, 2, 1>; };
+// 2^13 rows end on a radix-4 step (32 contiguous bytes per lane) since r03: <4,4,3,2> 92.4-94.0 us against
+// <4,4,4,1> 94.2-95.0 forward, inverse level (profiles/r03/asm_stages_ab.txt (5)); the table prefix the lower
+// steps read from LDS stays 511 entries.  (<3,4,4,2> is as fast but doubles that prefix; <4,4,2,3> is 3 %
+// slower forward and 2 % faster inverse.)
 #if SVENTT_PAIR
 // first step radix-8 on two neighbouring elements (16-byte loads), last step radix-4 (32 bytes per lane)
 template <> struct RowSteps<13> { using type = Steps<3, 4, 4, 2>; };
+#elif defined(SVENTT_ROW13_STEPS)  // A/B builds, e.g. -DSVENTT_ROW13_STEPS=4,4,4,1 (r02)
+template <> struct RowSteps<13> { using type = Steps<SVENTT_ROW13_STEPS>; };
+#else
+template <> struct RowSteps<13> { using type = Steps<4, 4, 3, 2>; };
+#endif
+#if defined(SVENTT_ROW12_STEPS)  // A/B builds
+template <> struct RowSteps<12> { using type = Steps<SVENTT_ROW12_STEPS>; };
 #endif
 
 constexpr int REG_LOGE = 4;

@@ -26,8 +26,12 @@ __device__ __forceinline__ void run_steps(const PassArgs &a, const typename TN::
 
 // E = 16 tiles are sized for four waves per SIMD (two 512-thread workgroups per CU with their
 // 64 KiB tiles, or four 256-thread ones): keep the register allocator inside 128 VGPRs.
+#ifndef SVENTT_KERNEL_ALIGN
+#define SVENTT_KERNEL_ALIGN 256  // (the toolchain's default for kernel entry points)
+#endif
 template <class TN>
-__global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1) void tile_kernel(const PassArgs a) {
+__global__ __launch_bounds__(TN::NT, (TN::LOGE == 4 && TN::NT >= 64) ? 4 : 1)
+__attribute__((aligned(SVENTT_KERNEL_ALIGN))) void tile_kernel(const PassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *lds = reinterpret_cast<u64 *>(smem);
   const typename TN::Tile t = TN::locate(a, blockIdx.x);

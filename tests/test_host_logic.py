@@ -186,11 +186,11 @@ def test_lds_swizzle_is_a_bijection_and_conflict_free():
         n = 1 << logt
         phys = np.array([L.sim_lds_phys(i) for i in range(n)])
         assert sorted(phys) == list(range(n))
-    # row tile 2^13 with steps (4,4,4,1), E = 16: thread tid, set g -> element indices
+    # row tile 2^13 with steps (4,4,3,2), E = 16: thread tid, set g -> element indices
     logt, nt = 13, 512
     worst = 0
     hi = 13
-    for k in (4, 4, 4, 1):
+    for k in (4, 4, 3, 2):
         lo = hi - k
         for v in range(1 << k):
             for g in range(16 >> k):
@@ -215,8 +215,8 @@ def test_set_mappings_are_bijective_and_wave_local():
     L = simlib.load()
     assert L.sim_check_set_mappings() > 200  # tile shapes checked (negative: the first bad one)
     # the two N = 2^24 kernels: one workgroup barrier per tile (r01: three and two)
-    assert L.sim_group_barriers(0, 13, 0, 0, 0, 4) == 1   # ROW 2^13 forward, Steps<4,4,4,1>
-    assert L.sim_group_barriers(1, 11, 0, 1, 2, 4) == 1   # COL 2^11 x T4 forward, Steps<4,4,3>
+    assert L.sim_group_barriers(0, 13, 0, 0, 0, 4) == 1   # ROW 2^13 forward, Steps<4,4,3,2>
+    assert L.sim_group_barriers(1, 11, 0, 1, 2, 4) == 1   # COL 2^11 x T4 forward, Steps<4,3,4>
     assert L.sim_group_barriers(0, 13, 1, 0, 0, 4) == 1 and L.sim_group_barriers(1, 11, 1, 1, 2, 4) == 1
 
 
