@@ -29,7 +29,11 @@ template <> struct DefaultSteps<6> { using type = Steps<4, 2>; };
 template <> struct DefaultSteps<7> { using type = Steps<4, 3>; };
 template <> struct DefaultSteps<8> { using type = Steps<4, 4>; };
 template <> struct DefaultSteps<9> { using type = Steps<4, 4, 1>; };
-template <> struct DefaultSteps<10> { using type = Steps<4, 4, 2>; };
+#if defined(SVENTT_COL10_STEPS)  // A/B builds
+template <> struct DefaultSteps<10> { using type = Steps<SVENTT_COL10_STEPS>; };
+#else
+template <> struct DefaultSteps<10> { using type = Steps<3, 4, 3>; };  // r03: 30.6 against <4,4,2> 31.5 us in the 2^22 plan
+#endif
 // 2^11 (the column tile of the 2^24 plan): radix-8 in the middle.  r03 A/B over eight alternating rounds and
 // a duplicate baseline (profiles/r03/asm_stages_ab.txt (5)): <4,3,4> 99.7-103.0 us against <4,4,3> 103.6-106.0
 // forward, 104.5-106.0 against 106.7-107.2 inverse.  -DSVENTT_COL11_STEPS=4,4,3 rebuilds r02's order.
@@ -38,7 +42,11 @@ template <> struct DefaultSteps<11> { using type = Steps<SVENTT_COL11_STEPS>; };
 #else
 template <> struct DefaultSteps<11> { using type = Steps<4, 3, 4>; };
 #endif
+#if defined(SVENTT_COL12_STEPS)  // A/B builds (also the default of 2^12 rows)
+template <> struct DefaultSteps<12> { using type = Steps<SVENTT_COL12_STEPS>; };
+#else
 template <> struct DefaultSteps<12> { using type = Steps<4, 4, 4>; };
+#endif
 template <> struct DefaultSteps<13> { using type = Steps<4, 4, 4, 1>; };
 
 // ROW tiles end on a short step where that helps: a last step of k stages leaves each thread
@@ -63,8 +71,13 @@ template <> struct RowSteps<13> { using type = Steps<SVENTT_ROW13_STEPS>; };
 #else
 template <> struct RowSteps<13> { using type = Steps<4, 4, 3, 2>; };
 #endif
+// 2^12 rows (BASELINE config #4, and the row pass of 2^22, 2^23 and the large plans): two radix-8 steps in the
+// middle and a radix-4 end: <4,3,3,2> 324.0 us against <4,4,4> 335.2 for 2^14 transforms forward (-3.4 %), inverse
+// level (profiles/r03/asm_stages_ab.txt (5)).
 #if defined(SVENTT_ROW12_STEPS)  // A/B builds
 template <> struct RowSteps<12> { using type = Steps<SVENTT_ROW12_STEPS>; };
+#else
+template <> struct RowSteps<12> { using type = Steps<4, 3, 3, 2>; };
 #endif
 
 constexpr int REG_LOGE = 4;

@@ -37,7 +37,7 @@ if __name__ == "__main__":
     shapes = {
         "row 2^13 (4,4,3,2)": (13, 0, 13, 4, (4, 4, 3, 2)),
         "row 2^13 (4,4,4,1) r02": (13, 0, 13, 4, (4, 4, 4, 1)),
-        "row 2^12 (4,4,4)": (12, 0, 12, 4, (4, 4, 4)),
+        "row 2^12 (4,3,3,2)": (12, 0, 12, 4, (4, 3, 3, 2)),
         "col 2^11 T4 (4,3,4)": (13, 2, 11, 4, (4, 3, 4)),
         "col 2^11 T4 (4,4,3) r02": (13, 2, 11, 4, (4, 4, 3)),
         "col 2^11 T8 (4,4,3)": (14, 3, 11, 4, (4, 4, 3)),
