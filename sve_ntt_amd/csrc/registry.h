@@ -80,6 +80,16 @@ template <> struct RowSteps<12> { using type = Steps<SVENTT_ROW12_STEPS>; };
 template <> struct RowSteps<12> { using type = Steps<4, 3, 3, 2>; };
 #endif
 
+// The two directions are separate kernels and need not cut their stages alike: the inverse 2^13 row tile runs
+// <4,4,2,3> (it starts, from HBM, with the radix-8 step and ends on the radix-16 one): 86.9-89.9 us against
+// 88.3-92.3 with the forward order (profiles/r03/asm_stages_ab.txt (5)).  -DSVENTT_ROW13_INV_STEPS=... for A/B.
+template <int LOGL, int MODE> struct RowStepsDir { using type = typename RowSteps<LOGL>::type; };
+#if defined(SVENTT_ROW13_INV_STEPS)
+template <> struct RowStepsDir<13, 1> { using type = Steps<SVENTT_ROW13_INV_STEPS>; };
+#elif !SVENTT_PAIR && !defined(SVENTT_ROW13_STEPS)
+template <> struct RowStepsDir<13, 1> { using type = Steps<4, 4, 2, 3>; };
+#endif
+
 constexpr int REG_LOGE = 4;
 // ROW tiles are 2^12 elements (256 threads) unless the row itself is longer.
 constexpr int row_logt(int logl) { return logl > 12 ? logl : 12; }
@@ -90,7 +100,7 @@ constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
 
 template <int LOGL, int MODE, bool FLAG, int ARITH = ARITH_MONT>
 using RowTile =
-    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowSteps<LOGL>::type, ARITH>;
+    TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowStepsDir<LOGL, MODE>::type, ARITH>;
 template <int LOGL, int MODE, int ARITH = ARITH_MONT, bool TWOLVL = false>
 using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
                         typename DefaultSteps<LOGL>::type, ARITH, TWOLVL>;
