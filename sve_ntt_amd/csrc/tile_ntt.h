@@ -511,6 +511,18 @@ struct TileNTT {
       twist_apply<3>(x, f3, zr, c);
     }
   }
+  // the same with the first two groups' factors already requested (Montgomery / Goldilocks tables)
+  template <int k, int LO>
+  __device__ __forceinline__ static void twist_all2(const PassArgs &a, const Tile &t, u64 (&x)[E],
+                                                    const u32 (&I0)[E >> k], const TwistFactors &f0,
+                                                    const TwistFactors &f1, u32 (&zr)[4], const AsmConsts &c) {
+    const TwistFactors f2 = twist_load<k, LO, 2>(a, t, I0);
+    twist_apply<0>(x, f0, zr, c);
+    const TwistFactors f3 = twist_load<k, LO, 3>(a, t, I0);
+    twist_apply<1>(x, f1, zr, c);
+    twist_apply<2>(x, f2, zr, c);
+    twist_apply<3>(x, f3, zr, c);
+  }
 
   // Operands of the fused pointwise product (ROW forward with FLAG) for x[4 GRP .. 4 GRP + 3].
   struct Operands {
@@ -586,6 +598,12 @@ struct TileNTT {
       w0 = group_twiddles<k, LO, lo, 0, 0>(a, s_low, lds);
       w1 = group_twiddles<k, LO, lo, 0, 1>(a, s_low, lds);
     }
+#if !defined(SVENTT_TWIST_IN_EARLY)
+#define SVENTT_TWIST_IN_EARLY 0  // 1: an inverse column tile asks for its first twist factors BEFORE its data (A/B)
+#endif
+    TwistFactors fin0, fin1;
+    if constexpr (twist_in && SVENTT_TWIST_IN_EARLY != 0) fin0 = twist_load<k, LO, 0>(a, t, I0);
+    if constexpr (twist_in && SVENTT_TWIST_IN_EARLY == 2 && ARITH != ARITH_SHOUP) fin1 = twist_load<k, LO, 1>(a, t, I0);
     exchange_sync<SYNC>();
     SVENTT_STAMP(lds, TR + 1);
     if constexpr (tw_in_lds && TWW == 1) {  // (two-word twiddles are read group by group: stages_asm)
@@ -639,7 +657,12 @@ struct TileNTT {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the data (and everything asked for before it) is here
     SVENTT_STAMP(lds, TR + 3);
 #endif
-    if constexpr (twist_in) twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), zr, c);
+    if constexpr (twist_in && SVENTT_TWIST_IN_EARLY == 2 && ARITH != ARITH_SHOUP)
+      twist_all2<k, LO>(a, t, x, I0, fin0, fin1, zr, c);
+    else if constexpr (twist_in && SVENTT_TWIST_IN_EARLY != 0)
+      twist_all<k, LO>(a, t, x, I0, fin0, zr, c);
+    else if constexpr (twist_in)
+      twist_all<k, LO>(a, t, x, I0, twist_load<k, LO, 0>(a, t, I0), zr, c);
     // ---- k fused stages ------------------------------------------------------
     TwistFactors f0;
     Operands o0;
