@@ -95,7 +95,7 @@ class ShardedNTT:
     ``src``/``dst`` are this rank's ``n / world`` elements (int64 tensors holding
     uint64 residues): the column slab on the natural-order side, the row block on
     the bit-reversed side.  ``chunks``: pieces the exchange is pipelined in
-    (default: env SVENTT_A2A_CHUNKS, else 1 for two ranks and 4 otherwise; reduced to what
+    (default: env SVENTT_A2A_CHUNKS, else 4; reduced to what
     the tile counts allow).
     """
 
@@ -115,11 +115,13 @@ class ShardedNTT:
         self.engine = engine or HipShardEngine(modulus, n, r_log2, self.rank, self.world)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if engine is None else "cpu"
-        # Two ranks exchange half of their data over ONE xGMI link: the exchange is several times
-        # longer than the column pass, there is little to hide and cutting the pass into four
-        # launches costs 139 against 120 us (profiles/r01/ubench_copy_and_sharded_local.txt), so the
-        # default is one launch per phase there and four chunks from four ranks on.
-        default_chunks = "1" if self.world == 2 else "4"
+        # Four chunks whatever the rank count: the exchange is the long pole (two ranks move half of
+        # their data over ONE xGMI link, eight ranks 7/8 over seven), and with K chunks the local passes
+        # cost local/K + (what the exchange does not cover) instead of all of local.  Cutting the column
+        # pass into four launches costs 139 against 120 us per 2^24 elements
+        # (profiles/r01/ubench_copy_and_sharded_local.txt), far less than it hides.  (r01/r02 ran two
+        # ranks unpipelined.)
+        default_chunks = "4"
         want = chunks if chunks is not None else int(os.environ.get("SVENTT_A2A_CHUNKS", default_chunks))
         k = max(1, want)
         while k > 1 and any(lim % k for lim in self.engine.chunk_limits):
