@@ -121,6 +121,27 @@ bool run(ncclComm_t comm, unsigned log2n, unsigned r_log2, unsigned chunks, bool
       ok = false;
     }
   }
+  // timing of the pipeline (closed-form cases only): the exchange is a copy of the rank's data to itself, so
+  // what this shows is whether the chunks' exchanges run beside the passes of their neighbours
+  if (closed && ok) {
+    hipEvent_t e0{}, e1{};
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    for (int i{}; i < 3; ++i) (void)sventt_sharded_forward(cols, rows, comm, d_dst, d_src, d_work, d_recv, chunks, stream);
+    HIP_OK(hipEventRecord(e0, stream));
+    const int reps{10};
+    for (int i{}; i < reps; ++i) {
+      if (sventt_sharded_forward(cols, rows, comm, d_dst, d_src, d_work, d_recv, chunks, stream)) return false;
+    }
+    HIP_OK(hipEventRecord(e1, stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms{};
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("   timing: %.3f ms per forward transform of 2^%u points with %u chunk(s), exchange = RCCL self send/recv\n",
+                ms / reps, log2n, chunks);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
   // a communicator of the wrong size is refused before anything is enqueued
   std::printf("%s RCCL one-rank sharded transform: n=2^%u, R=2^%u, %u chunks (%u RCCL group calls per direction), %s check\n"
               "   plan: %s | all-to-all (RCCL, self) | %s\n",
@@ -155,6 +176,7 @@ int main(int argc, char **argv) {
   ok &= run(comm, 22, 8, 4, false);   // C = 2^14: col 2^2 (two-level form) | row 2^12
   ok &= run(comm, 22, 6, 1, false);   // C = 2^16: col 2^3 | row 2^13, one chunk
   ok &= run(comm, 27, 11, 4, true);   // the per-rank size of BASELINE configs[4]
+  ok &= run(comm, 27, 11, 1, true);   // the same unpipelined (timing comparison)
   // plans of two ranks against the one-rank communicator: refused, nothing enqueued
   {
     sventt_plan *cols{}, *rows{};
