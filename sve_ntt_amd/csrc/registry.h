@@ -101,16 +101,23 @@ constexpr int col_f0(int logl) { return logl >= 9 ? 3 : 12 - logl; }
 template <int LOGL, int MODE, bool FLAG, int ARITH = ARITH_MONT>
 using RowTile =
     TileNTT<row_logt(LOGL), 0, LOGL, REG_LOGE, MODE, FLAG, typename RowStepsDir<LOGL, MODE>::type, ARITH>;
+// The step order of a column tile may depend on the arithmetic back end: the FixedPoint64 kernels (two words per
+// twiddle, other register pressure) run the 2^11 tile 2 % faster with r02's <4,4,3> (198.9-200.5 against
+// 203.1-204.8 us at N = 2^24, tools/ab_shoup.sh).
+template <int LOGL, int ARITH> struct ColSteps { using type = typename DefaultSteps<LOGL>::type; };
+#if !defined(SVENTT_COL11_STEPS)
+template <> struct ColSteps<11, ARITH_SHOUP> { using type = Steps<4, 4, 3>; };
+#endif
 template <int LOGL, int MODE, int ARITH = ARITH_MONT, bool TWOLVL = false>
 using ColTile = TileNTT<LOGL + col_f0(LOGL), col_f0(LOGL), LOGL, REG_LOGE, MODE, true,
-                        typename DefaultSteps<LOGL>::type, ARITH, TWOLVL>;
+                        typename ColSteps<LOGL, ARITH>::type, ARITH, TWOLVL>;
 
 // Narrow COL tiles (T = 8 whatever the column length) for blocks with fewer
 // columns than the wide tile wants; tiny tiles, only met at small n.
 constexpr int NARROW_F0 = 3;
 template <int LOGL, int MODE, int ARITH = ARITH_MONT>
 using ColTileNarrow = TileNTT<LOGL + NARROW_F0, NARROW_F0, LOGL, REG_LOGE, MODE, true,
-                              typename DefaultSteps<LOGL>::type, ARITH>;
+                              typename ColSteps<LOGL, ARITH>::type, ARITH>;
 
 // Slim COL tiles (T = 4, 32-byte segments; the XCD-aware tile order of
 // TileNTT::locate lets one L2 merge the two halves of a 64-byte line): half the
@@ -118,13 +125,13 @@ using ColTileNarrow = TileNTT<LOGL + NARROW_F0, NARROW_F0, LOGL, REG_LOGE, MODE,
 constexpr int SLIM_F0 = 2;
 template <int LOGL, int MODE, int ARITH = ARITH_MONT, bool TWOLVL = false>
 using ColTileSlim = TileNTT<LOGL + SLIM_F0, SLIM_F0, LOGL, REG_LOGE, MODE, true,
-                            typename DefaultSteps<LOGL>::type, ARITH, TWOLVL>;
+                            typename ColSteps<LOGL, ARITH>::type, ARITH, TWOLVL>;
 // Thin COL tiles (T = 2, 16-byte segments): a quarter of the wide tile's LDS, 2^11 columns in 256 threads --
 // four independent workgroups per CU instead of two (experiment, SVENTT_COL_THIN=1).
 constexpr int THIN_F0 = 1;
 template <int LOGL, int MODE, int ARITH = ARITH_MONT>
 using ColTileThin = TileNTT<LOGL + THIN_F0, THIN_F0, LOGL, REG_LOGE, MODE, true,
-                            typename DefaultSteps<LOGL>::type, ARITH>;
+                            typename ColSteps<LOGL, ARITH>::type, ARITH>;
 // Two-level variants of both (tile_ntt.h: TWOLVL): the first pass of the sharded row transform when it
 // is longer than the rank count, i.e. the gather of the received pieces fused with the column pass
 // that used to follow it.  Lengths 2^2 .. 2^12 (rank count x inner column length).
