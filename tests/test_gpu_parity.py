@@ -570,26 +570,25 @@ def test_plan_refuses_every_launch_from_another_device(eng):
     torch.cuda.synchronize()
 
 
-def test_failed_host_register_leaves_no_sticky_error(eng, port):
-    """sventt_host_register is used best-effort (PageMemory); a failing hipHostRegister must
-    not leave HIP's per-thread last error behind for the next launch to report as its own."""
+def test_failed_host_unregister_leaves_no_sticky_error(eng, port):
+    """sventt_host_register/_unregister are used best-effort (PageMemory); a failing HIP call in
+    them must not leave HIP's per-thread last error behind for the next launch to report as its own
+    (launch_tile returns hipGetLastError()).  Provoked the benign way: unregistering a live, valid buffer
+    that was never registered."""
     from sve_ntt_amd import _lib
     L = _lib.load()
     buf = np.zeros(1 << 12, dtype=np.uint64)
-    assert L.sventt_host_register(buf.ctypes.data, buf.nbytes) == 0
-    assert L.sventt_host_register(0x10000, 1 << 16) != 0                   # not mapped: hipHostRegister fails
-    assert b"hipHostRegister" in L.sventt_last_error()
+    assert L.sventt_host_unregister(buf.ctypes.data) != 0                  # never registered: HIP refuses
+    assert b"hipHostUnregister" in L.sventt_last_error()
     m = 1 << 12
     ntt = eng.NTT(eng.Modulus(P, G), m)
     src = port.fill_splitmix(m, 5, P)
     out = torch.empty(m, dtype=torch.int64, device="cuda")
     ntt.compute_forward(out, dev(src))                                     # must not see the stale error
     assert np.array_equal(host(out), port.forward(src, P, G))
+    assert L.sventt_host_register(buf.ctypes.data, buf.nbytes) == 0        # and the pair still works
     assert L.sventt_host_unregister(buf.ctypes.data) == 0
-    assert L.sventt_host_unregister(0x10000) != 0                          # never registered
-    ntt.compute_forward(out)
     torch.cuda.synchronize()
-    assert np.array_equal(host(out), port.forward(port.forward(src, P, G), P, G))
 
 
 def test_sharded_columns_entry_point_equals_chunked_path(eng):
